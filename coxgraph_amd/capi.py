@@ -1,0 +1,285 @@
+"""ctypes binding of the C ABI declared in include/coxgraph_hip.h.
+
+The binding is generic over (shared library, symbol prefix): the product engine is
+``coxgraph_amd/lib/libcoxgraph_hip.so`` with prefix ``cox_``; the test suite loads the CPU oracle
+(``oracle/libcoxoracle.so``, prefix ``coxo_``) through the same classes so parity tests read the
+same on both sides.  Nothing in this package loads the oracle.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+COX_OK = 0
+STATUS = {
+    0: "COX_OK", -1: "COX_ERR_INVALID_ARG", -2: "COX_ERR_NO_DEVICE", -3: "COX_ERR_OUT_OF_MEMORY",
+    -4: "COX_ERR_POOL_EXHAUSTED", -5: "COX_ERR_INDEX_RANGE", -6: "COX_ERR_UNSUPPORTED",
+    -7: "COX_ERR_BUFFER_TOO_SMALL", -8: "COX_ERR_INTERNAL",
+}
+METHODS = {"simple": 0, "merged": 1, "fast": 2}
+VOXELS_PER_BLOCK = 4096
+
+
+class CoxError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__(f"{what}: {STATUS.get(status, status)}")
+        self.status = status
+
+
+class TsdfConfig(C.Structure):
+    """cox_tsdf_config (voxblox TsdfIntegratorBase::Config)."""
+    _fields_ = [
+        ("default_truncation_distance", C.c_float), ("max_weight", C.c_float),
+        ("voxel_carving_enabled", C.c_int32), ("min_ray_length_m", C.c_float),
+        ("max_ray_length_m", C.c_float), ("use_const_weight", C.c_int32), ("allow_clear", C.c_int32),
+        ("use_weight_dropoff", C.c_int32), ("use_sparsity_compensation_factor", C.c_int32),
+        ("sparsity_compensation_factor", C.c_float), ("integrator_threads", C.c_int32),
+        ("integration_order_mode", C.c_int32), ("enable_anti_grazing", C.c_int32),
+        ("start_voxel_subsampling_factor", C.c_float), ("max_consecutive_ray_collisions", C.c_int32),
+        ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float),
+        ("merged_bundle_order", C.c_int32), ("fast_exact_sets", C.c_int32),
+    ]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_points", "n_valid", "n_rays", "n_updates", "n_touched_voxels",
+                                          "n_touched_blocks", "n_new_blocks")]
+
+    def asdict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RegConfig(C.Structure):
+    _fields_ = [("no_correspondence_cost", C.c_double)]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One loaded implementation of the C ABI."""
+
+    def __init__(self, lib_path, prefix):
+        if not os.path.exists(lib_path):
+            raise FileNotFoundError(lib_path)
+        self.lib = C.CDLL(lib_path)
+        self.prefix = prefix
+        self.path = lib_path
+
+    def fn(self, name, restype=C.c_int):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        return f
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    def check(self, status, what):
+        if status != COX_OK:
+            raise CoxError(status, what)
+
+    def default_config(self, **overrides):
+        cfg = TsdfConfig()
+        self.fn("tsdf_config_default", None)(C.byref(cfg))
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            setattr(cfg, k, v)
+        return cfg
+
+    def device_count(self):
+        return int(self.fn("device_count")()) if self.has("device_count") else 0
+
+
+class Layer:
+    """voxblox::Layer<TsdfVoxel> (cox_layer_t)."""
+
+    def __init__(self, eng, voxel_size, voxels_per_side=16, device=0, capacity_blocks=0):
+        self.eng = eng
+        self.voxel_size = float(voxel_size)
+        self.h = C.c_void_p()
+        eng.check(eng.fn("layer_create")(C.c_float(voxel_size), C.c_int(voxels_per_side), C.c_int(device),
+                                         C.c_uint64(capacity_blocks), C.byref(self.h)), "layer_create")
+
+    def close(self):
+        if self.h:
+            self.eng.fn("layer_destroy", None)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):  # removeAllBlocks
+        self.eng.check(self.eng.fn("layer_clear")(self.h), "layer_clear")
+
+    def stats(self):
+        n, b = C.c_uint64(), C.c_uint64()
+        self.eng.check(self.eng.fn("layer_stats")(self.h, C.byref(n), C.byref(b)), "layer_stats")
+        return int(n.value), int(b.value)
+
+    def download(self):
+        """serializeLayerAsMsg: (block_idx int32[n,3], words uint32[n,4096,3]) sorted by (z,y,x)."""
+        n = C.c_uint64()
+        f = self.eng.fn("layer_download")
+        self.eng.check(f(self.h, None, None, C.c_uint64(0), C.byref(n)), "layer_download(query)")
+        nb = int(n.value)
+        idx = np.zeros((nb, 3), np.int32)
+        vox = np.zeros((nb, VOXELS_PER_BLOCK, 3), np.uint32)
+        if nb:
+            self.eng.check(f(self.h, _fp(idx), _fp(vox), C.c_uint64(nb), C.byref(n)), "layer_download")
+        return idx, vox
+
+    def upload(self, idx, vox, action=0):
+        idx = np.ascontiguousarray(idx, np.int32)
+        vox = np.ascontiguousarray(vox, np.uint32)
+        assert vox.shape == (idx.shape[0], VOXELS_PER_BLOCK, 3)
+        self.eng.check(self.eng.fn("layer_upload")(self.h, _fp(idx), _fp(vox), C.c_uint64(idx.shape[0]), C.c_int(action)),
+                       "layer_upload")
+
+
+class Integrator:
+    """voxblox::TsdfIntegratorBase (cox_integrator_t)."""
+
+    def __init__(self, eng, layer, cfg, method):
+        self.eng, self.layer = eng, layer
+        self.h = C.c_void_p()
+        m = METHODS[method] if isinstance(method, str) else int(method)
+        eng.check(eng.fn("integrator_create")(layer.h, C.byref(cfg), C.c_int(m), C.byref(self.h)), "integrator_create")
+
+    def close(self):
+        if self.h:
+            self.eng.fn("integrator_destroy", None)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def integrate_points(self, T_G_C, xyz, rgba=None, freespace=False):
+        """integratePointCloud(T_G_C, points_C, colors, freespace_points) with host buffers."""
+        T = np.ascontiguousarray(T_G_C, np.float32)
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert T.shape == (7,) and xyz.ndim == 2 and xyz.shape[1] == 3
+        n = xyz.shape[0]
+        if rgba is not None:
+            rgba = np.ascontiguousarray(rgba, np.uint8)
+            assert rgba.shape == (n, 4)
+        self.eng.check(self.eng.fn("integrate_points")(self.h, _fp(T), _fp(xyz), _fp(rgba) if rgba is not None else None,
+                                                       C.c_uint64(n), C.c_int(int(freespace))), "integrate_points")
+
+    def integrate_points_dev(self, T_G_C, xyz_ptr, rgba_ptr, n, freespace=False):
+        T = np.ascontiguousarray(T_G_C, np.float32)
+        self.eng.check(self.eng.fn("integrate_points_dev")(self.h, _fp(T), C.c_void_p(xyz_ptr), C.c_void_p(rgba_ptr or 0),
+                                                           C.c_uint64(n), C.c_int(int(freespace))), "integrate_points_dev")
+
+    def integrate_depth_dev(self, T_G_C, depth_ptr, rgba_ptr, w, h, K):
+        T = np.ascontiguousarray(T_G_C, np.float32)
+        K = np.ascontiguousarray(K, np.float32)
+        self.eng.check(self.eng.fn("integrate_depth_dev")(self.h, _fp(T), C.c_void_p(depth_ptr), C.c_void_p(rgba_ptr or 0),
+                                                          C.c_int(w), C.c_int(h), _fp(K)), "integrate_depth_dev")
+
+    def sync(self):
+        self.eng.check(self.eng.fn("integrator_sync")(self.h), "integrator_sync")
+
+    def last_stats(self):
+        s = FrameStats()
+        self.eng.check(self.eng.fn("integrator_last_stats")(self.h, C.byref(s)), "integrator_last_stats")
+        return s.asdict()
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        self.eng.check(self.eng.fn("integrator_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))),
+                       "integrator_kernel_time")
+        return float(ms.value), int(n.value)
+
+
+class RegPoints:
+    def __init__(self, eng, pts, device=0):
+        self.eng = eng
+        pts = np.ascontiguousarray(pts, np.float32)
+        assert pts.ndim == 2 and pts.shape[1] == 5
+        self.n = pts.shape[0]
+        self.h = C.c_void_p()
+        eng.check(eng.fn("regpoints_create")(C.c_int(device), _fp(pts), C.c_uint64(self.n), C.byref(self.h)), "regpoints_create")
+
+    def close(self):
+        if self.h:
+            self.eng.fn("regpoints_destroy", None)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Registration:
+    """voxgraph::RegistrationCostFunction for one (reference points, reading layer) pair."""
+
+    def __init__(self, eng, ref_points, reading_layer, no_correspondence_cost=0.0):
+        self.eng, self.ref, self.reading = eng, ref_points, reading_layer
+        cfg = RegConfig(no_correspondence_cost)
+        self.h = C.c_void_p()
+        eng.check(eng.fn("reg_create")(ref_points.h, reading_layer.h, C.byref(cfg), C.byref(self.h)), "reg_create")
+
+    def close(self):
+        if self.h:
+            self.eng.fn("reg_destroy", None)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _args(self, pose_ref, pose_read, sample_idx):
+        pr = np.ascontiguousarray(pose_ref, np.float64)
+        pd = np.ascontiguousarray(pose_read, np.float64)
+        assert pr.shape == (4,) and pd.shape == (4,)
+        if sample_idx is None:
+            return pr, pd, None, self.ref.n
+        si = np.ascontiguousarray(sample_idx, np.uint32)
+        return pr, pd, si, si.shape[0]
+
+    def evaluate(self, pose_ref, pose_read, sample_idx=None, jacobians=True):
+        """CostFunction::Evaluate -> (residuals[n], J_ref[n,4], J_read[n,4])."""
+        pr, pd, si, n = self._args(pose_ref, pose_read, sample_idx)
+        r = np.zeros(n, np.float64)
+        jf = np.zeros((n, 4), np.float64) if jacobians else None
+        jr = np.zeros((n, 4), np.float64) if jacobians else None
+        self.eng.check(self.eng.fn("reg_evaluate")(self.h, _fp(pr), _fp(pd), _fp(si) if si is not None else None, C.c_uint64(n),
+                                                   _fp(r), _fp(jf) if jacobians else None, _fp(jr) if jacobians else None),
+                       "reg_evaluate")
+        return r, jf, jr
+
+    def normal_eq(self, pose_ref, pose_read, sample_idx=None):
+        pr, pd, si, n = self._args(pose_ref, pose_read, sample_idx)
+        H = np.zeros((8, 8), np.float64)
+        b = np.zeros(8, np.float64)
+        cost, nc = C.c_double(), C.c_uint64()
+        self.eng.check(self.eng.fn("reg_normal_eq")(self.h, _fp(pr), _fp(pd), _fp(si) if si is not None else None, C.c_uint64(n),
+                                                    _fp(H), _fp(b), C.byref(cost), C.byref(nc)), "reg_normal_eq")
+        return H, b, float(cost.value), int(nc.value)
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        self.eng.check(self.eng.fn("reg_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))), "reg_kernel_time")
+        return float(ms.value), int(n.value)
+
+
+# ---- wire-format helpers (voxblox_msgs/Block data words) -----------------------------------------
+def words_to_fields(vox):
+    """uint32[...,3] wire words -> (distance f32, weight f32, rgba u8[...,4])."""
+    vox = np.ascontiguousarray(vox, np.uint32)
+    d = vox[..., 0].copy().view(np.float32)
+    w = vox[..., 1].copy().view(np.float32)
+    c = vox[..., 2]
+    rgba = np.stack([(c >> 24) & 255, (c >> 16) & 255, (c >> 8) & 255, c & 255], axis=-1).astype(np.uint8)
+    return d, w, rgba

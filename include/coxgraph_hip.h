@@ -1,0 +1,175 @@
+/*
+ * coxgraph_hip.h -- C ABI of the MI355X-native TSDF fusion + submap registration engine.
+ *
+ * This is the drop-in boundary for the ONE data-parallel hot path of mfkiwl/coxgraph
+ * (SURVEY.md section 8).  The reference has no FFI layer of its own: the seam is C++ virtual
+ * dispatch into the un-vendored voxblox / voxgraph forks.  Every entry point below names the
+ * reference interface (file:line under /root/reference) whose work it replaces; the thin C++
+ * adapter classes that give these entry points the reference's own signatures live in
+ * coxgraph_amd/host/ (see INTEGRATION.md for the binding a coxgraph maintainer would add).
+ *
+ * Conventions
+ *  - every function returns COX_OK (0) or a negative cox_status; no exception crosses the ABI
+ *  - handles are opaque; one handle = one GPU + one HIP stream; handles are NOT thread-safe
+ *    (mirror: one ROS callback thread drives an integrator, tsdf_recover.h:71-77), but distinct
+ *    handles may be used from distinct threads (mirror: Ceres calls Evaluate on different
+ *    residual blocks from up to 4 threads, backend/pose_graph.h:63)
+ *  - input buffers are HOST pointers borrowed for the duration of the call unless the name
+ *    says _dev (then they are device pointers valid on the handle's GPU, e.g. a torch tensor's
+ *    data_ptr()); the engine owns all device memory it allocates
+ *  - poses T_G_C are 7 floats: unit quaternion (w,x,y,z) then translation (x,y,z)  [minkindr
+ *    QuatTransformationTemplate<float>, used as voxblox::Transformation]
+ *  - 4-DoF poses are 4 doubles (x, y, z, yaw)  [voxgraph Pose4D; pose graph is 4-DoF, see
+ *    coxgraph/include/coxgraph/server/backend/node_collection.h:22-24]
+ */
+#ifndef COXGRAPH_HIP_H_
+#define COXGRAPH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cox_status {
+  COX_OK = 0,
+  COX_ERR_INVALID_ARG = -1,
+  COX_ERR_NO_DEVICE = -2,       /* no HIP device / HIP runtime call failed */
+  COX_ERR_OUT_OF_MEMORY = -3,   /* device allocation failed */
+  COX_ERR_POOL_EXHAUSTED = -4,  /* block pool or hash table full: layer was created too small */
+  COX_ERR_INDEX_RANGE = -5,     /* a voxel index left the +-2^20 range the packed keys support */
+  COX_ERR_UNSUPPORTED = -6,     /* valid in the reference, not implemented by this engine (yet) */
+  COX_ERR_BUFFER_TOO_SMALL = -7,
+  COX_ERR_INTERNAL = -8
+} cox_status;
+
+typedef struct cox_layer cox_layer_t;           /* voxblox::Layer<TsdfVoxel> on one GPU */
+typedef struct cox_integrator cox_integrator_t; /* voxblox::TsdfIntegratorBase */
+typedef struct cox_regpoints cox_regpoints_t;   /* voxgraph registration point set of a submap */
+typedef struct cox_reg cox_reg_t;               /* voxgraph::RegistrationCostFunction */
+
+/* integrator factory key: method in {"simple","merged","fast"}
+ * (coxgraph/config/tsdf_server_euroc.yaml:6, tsdf_server_default.yaml:6,
+ *  coxgraph_sim/launch/experiments/mav_3dplanning_2d3dhouse_two.launch:10) */
+typedef enum cox_method { COX_METHOD_SIMPLE = 0, COX_METHOD_MERGED = 1, COX_METHOD_FAST = 2 } cox_method;
+
+/* voxblox::TsdfIntegratorBase::Config as read by getTsdfIntegratorConfigFromRosParam
+ * (used by coxgraph/include/coxgraph/map_comm/tsdf_recover.h:48-50; keys in
+ *  coxgraph/config/tsdf_server_euroc.yaml:10-24).  cox_tsdf_config_default() fills the voxblox
+ * defaults. */
+typedef struct cox_tsdf_config {
+  float default_truncation_distance; /* truncation_distance */
+  float max_weight;
+  int32_t voxel_carving_enabled;
+  float min_ray_length_m;
+  float max_ray_length_m;
+  int32_t use_const_weight;
+  int32_t allow_clear;
+  int32_t use_weight_dropoff;
+  int32_t use_sparsity_compensation_factor;
+  float sparsity_compensation_factor;
+  int32_t integrator_threads;     /* CPU oracle only; the GPU engine ignores it */
+  int32_t integration_order_mode; /* 0 = "mixed" (voxblox default); others unsupported */
+  int32_t enable_anti_grazing;
+  float start_voxel_subsampling_factor; /* fast */
+  int32_t max_consecutive_ray_collisions; /* fast */
+  int32_t clear_checks_every_n_frames;    /* fast */
+  float max_integration_time_s;           /* fast; CPU oracle only */
+  int32_t merged_bundle_order;            /* CPU oracle only: 0 canonical, 1 libstdc++ map order */
+  int32_t fast_exact_sets;                /* CPU oracle only: 0 ApproxHashSet, 1 exact sets */
+} cox_tsdf_config;
+
+/* per-frame counters of the last cox_integrate_* call (used for the roofline accounting of
+ * B_frame = 16*n_valid + 24*n_touched_voxels) */
+typedef struct cox_frame_stats {
+  uint64_t n_points;         /* points handed in */
+  uint64_t n_valid;          /* points that passed isPointValid */
+  uint64_t n_rays;           /* rays cast (simple: n_valid, merged: bundles) */
+  uint64_t n_updates;        /* (ray, voxel) updates = updateTsdfVoxel calls */
+  uint64_t n_touched_voxels; /* distinct voxels updated */
+  uint64_t n_touched_blocks; /* distinct blocks visited */
+  uint64_t n_new_blocks;     /* blocks allocated by this frame */
+} cox_frame_stats;
+
+void cox_tsdf_config_default(cox_tsdf_config* cfg);
+const char* cox_status_string(int status);
+/* number of HIP devices visible (0 without a GPU); never fails */
+int cox_device_count(void);
+
+/* ---- Layer<TsdfVoxel>  ------------------------------------------------------------------- */
+/* voxblox::Layer<TsdfVoxel>(voxel_size, voxels_per_side) as owned by TsdfMap
+ * (tsdf_recover.h:48 getTsdfMapConfigFromRosParam).  voxels_per_side must be 16.
+ * capacity_blocks = size of the device block pool (49,152 B each); 0 picks a default. */
+int cox_layer_create(float voxel_size, int voxels_per_side, int device, uint64_t capacity_blocks, cox_layer_t** out);
+void cox_layer_destroy(cox_layer_t* layer);
+/* Layer::removeAllBlocks()  (tsdf_recover.h:62, src/client/map_server.cpp:65) */
+int cox_layer_clear(cox_layer_t* layer);
+/* Layer::getNumberOfAllocatedBlocks() / getMemorySize()  (map_server.h:142, tsdf_recover.h:92) */
+int cox_layer_stats(cox_layer_t* layer, uint64_t* n_blocks, uint64_t* memory_bytes);
+/* serializeLayerAsMsg<TsdfVoxel>(layer, only_updated=false, &msg)  (utils/msg_converter.h:49,
+ * map_server.cpp:88, tsdf_recover.h:95): block_idx_xyz gets 3 int32 per block, voxels_3u32 gets
+ * 4096*3 uint32 per block in voxblox_msgs/Block wire layout (distance bits, weight bits,
+ * a|b<<8|g<<16|r<<24).  Blocks are returned sorted by (z,y,x) so output is deterministic.
+ * Pass cap_blocks = 0 and NULL buffers to query n_blocks only. */
+int cox_layer_download(cox_layer_t* layer, int32_t* block_idx_xyz, uint32_t* voxels_3u32, uint64_t cap_blocks, uint64_t* n_blocks);
+/* deserializeMsgToLayer(msg, layer)  (utils/msg_converter.h:107): action 0 = update (overwrite
+ * blocks), 1 = merge (mergeVoxelAIntoVoxelB per voxel), 2 = reset (clear first, then update) */
+int cox_layer_upload(cox_layer_t* layer, const int32_t* block_idx_xyz, const uint32_t* voxels_3u32, uint64_t n_blocks, int action);
+
+/* ---- TsdfIntegratorBase -------------------------------------------------------------------- */
+/* TsdfIntegratorFactory::create(method, config, layer) */
+int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out);
+void cox_integrator_destroy(cox_integrator_t* integ);
+/* TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace_points)
+ * -- the call at coxgraph/include/coxgraph/map_comm/tsdf_recover.h:75.
+ * xyz: n*3 floats (camera frame), rgba: n*4 bytes or NULL. Host pointers. Synchronous. */
+int cox_integrate_points(cox_integrator_t* integ, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace);
+/* same, inputs already resident on the handle's GPU; asynchronous on the handle's stream */
+int cox_integrate_points_dev(cox_integrator_t* integ, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace);
+/* depth image front end (what depth_image_proc/point_cloud_xyzrgb does ahead of the tsdf_server,
+ * coxgraph/launch/cvg/tsdf_client0_cvg.launch:24-30): p_C = d*((u-cx)/fx,(v-cy)/fy,1), row-major
+ * point order, non-finite or <=0 depths dropped.  depth_dev: w*h floats in metres on the GPU;
+ * rgba_dev: w*h*4 bytes or NULL.  K = {fx, fy, cx, cy}.  Asynchronous. */
+int cox_integrate_depth_dev(cox_integrator_t* integ, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h,
+                            const float K[4]);
+/* wait for the handle's stream; returns any deferred device-side error (pool exhausted, ...) */
+int cox_integrator_sync(cox_integrator_t* integ);
+int cox_integrator_last_stats(cox_integrator_t* integ, cox_frame_stats* stats);
+/* HIP-event time of the dominant kernel over the calls since the last reset (bench.py roofline):
+ * accumulated milliseconds and launch count of the TSDF update ("apply") kernel */
+int cox_integrator_kernel_time(cox_integrator_t* integ, double* apply_ms, uint64_t* apply_launches, int reset);
+
+/* ---- registration (voxgraph RegistrationCostFunction) ------------------------------------- */
+typedef struct cox_reg_config {
+  double no_correspondence_cost; /* voxgraph registration.no_correspondence_cost, default 0 */
+} cox_reg_config;
+
+/* Registration points of the reference submap (VoxgraphSubmap::finishSubmap() builds them,
+ * called at utils/msg_converter.h:113): n * {x, y, z, distance, weight} floats. */
+int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, cox_regpoints_t** out);
+void cox_regpoints_destroy(cox_regpoints_t* pts);
+/* RegistrationConstraint::Config{first_submap_ptr, second_submap_ptr, registration{...}} as set up
+ * by PoseGraphInterface::addForceRegistrationConstraint (src/server/pose_graph_interface.cpp:88-105):
+ * reference = first submap's registration points, reading = second submap's TSDF layer. */
+int cox_reg_create(const cox_regpoints_t* reference, const cox_layer_t* reading, const cox_reg_config* cfg, cox_reg_t** out);
+void cox_reg_destroy(cox_reg_t* reg);
+/* ceres::CostFunction::Evaluate(parameters, residuals, jacobians): parameter blocks {4,4} =
+ * (reference pose, reading pose); residuals[n_res]; jacobians row-major n_res x 4, either may be
+ * NULL.  sample_idx = n_res indices into the registration points (the weighted sampler's draws,
+ * made explicit so both sides use the same ones) or NULL for "all points in order" (then n_res
+ * must equal the number of points, i.e. sampling_ratio = -1). Host output buffers. */
+int cox_reg_evaluate(cox_reg_t* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res,
+                     double* residuals, double* jac_ref, double* jac_read);
+/* Fused form: H = J^T J (8x8 row-major, J = [J_ref J_read]), b = J^T r (8), cost = 0.5*|r|^2,
+ * n_corr = residuals with a correspondence.  Block-parallel reduction on the GPU; only these
+ * 74 numbers cross PCIe. */
+int cox_reg_normal_eq(cox_reg_t* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res,
+                      double H[64], double b[8], double* cost, uint64_t* n_corr);
+/* HIP-event time of the registration kernel since last reset (bench.py) */
+int cox_reg_kernel_time(cox_reg_t* reg, double* ms, uint64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COXGRAPH_HIP_H_ */

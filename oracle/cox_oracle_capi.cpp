@@ -1,0 +1,290 @@
+// CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see cox_oracle.hpp header).
+//
+// C ABI of the oracle: the same entry points as include/coxgraph_hip.h with the prefix
+// `coxo_` instead of `cox_`, so tests can drive the oracle and the HIP engine through one
+// Python wrapper.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this.
+#include "../include/coxgraph_hip.h"
+#include "cox_oracle.hpp"
+
+#include <map>
+#include <tuple>
+
+using namespace coxo;
+
+struct coxo_layer {
+  Layer layer;
+  coxo_layer(float vs, int vps) : layer(vs, vps) {}
+};
+struct coxo_integrator {
+  std::unique_ptr<Integrator> integ;
+};
+struct coxo_regpoints {
+  std::vector<RegPoint> pts;
+};
+struct coxo_reg {
+  const coxo_regpoints* ref;
+  const coxo_layer* reading;
+  RegConfig cfg;
+};
+
+static TsdfConfig toCfg(const cox_tsdf_config* c) {
+  TsdfConfig o;
+  o.default_truncation_distance = c->default_truncation_distance;
+  o.max_weight = c->max_weight;
+  o.voxel_carving_enabled = c->voxel_carving_enabled != 0;
+  o.min_ray_length_m = c->min_ray_length_m;
+  o.max_ray_length_m = c->max_ray_length_m;
+  o.use_const_weight = c->use_const_weight != 0;
+  o.allow_clear = c->allow_clear != 0;
+  o.use_weight_dropoff = c->use_weight_dropoff != 0;
+  o.use_sparsity_compensation_factor = c->use_sparsity_compensation_factor != 0;
+  o.sparsity_compensation_factor = c->sparsity_compensation_factor;
+  o.integrator_threads = c->integrator_threads;
+  o.integration_order_mode = c->integration_order_mode;
+  o.enable_anti_grazing = c->enable_anti_grazing != 0;
+  o.start_voxel_subsampling_factor = c->start_voxel_subsampling_factor;
+  o.max_consecutive_ray_collisions = c->max_consecutive_ray_collisions;
+  o.clear_checks_every_n_frames = c->clear_checks_every_n_frames;
+  o.max_integration_time_s = c->max_integration_time_s;
+  o.merged_bundle_order = c->merged_bundle_order;
+  o.fast_exact_sets = c->fast_exact_sets;
+  return o;
+}
+
+extern "C" {
+
+void coxo_tsdf_config_default(cox_tsdf_config* c) {
+  TsdfConfig d;
+  c->default_truncation_distance = d.default_truncation_distance;
+  c->max_weight = d.max_weight;
+  c->voxel_carving_enabled = d.voxel_carving_enabled;
+  c->min_ray_length_m = d.min_ray_length_m;
+  c->max_ray_length_m = d.max_ray_length_m;
+  c->use_const_weight = d.use_const_weight;
+  c->allow_clear = d.allow_clear;
+  c->use_weight_dropoff = d.use_weight_dropoff;
+  c->use_sparsity_compensation_factor = d.use_sparsity_compensation_factor;
+  c->sparsity_compensation_factor = d.sparsity_compensation_factor;
+  c->integrator_threads = 1;
+  c->integration_order_mode = 0;
+  c->enable_anti_grazing = 0;
+  c->start_voxel_subsampling_factor = d.start_voxel_subsampling_factor;
+  c->max_consecutive_ray_collisions = d.max_consecutive_ray_collisions;
+  c->clear_checks_every_n_frames = d.clear_checks_every_n_frames;
+  c->max_integration_time_s = d.max_integration_time_s;
+  c->merged_bundle_order = 0;
+  c->fast_exact_sets = 0;
+}
+
+int coxo_layer_create(float voxel_size, int vps, int /*device*/, uint64_t /*capacity*/, coxo_layer** out) {
+  if (!out || !(voxel_size > 0.0f) || vps <= 0 || (vps & (vps - 1))) return COX_ERR_INVALID_ARG;
+  *out = new coxo_layer(voxel_size, vps);
+  return COX_OK;
+}
+void coxo_layer_destroy(coxo_layer* l) { delete l; }
+int coxo_layer_clear(coxo_layer* l) {
+  l->layer.removeAllBlocks();
+  return COX_OK;
+}
+int coxo_layer_stats(coxo_layer* l, uint64_t* n_blocks, uint64_t* bytes) {
+  if (n_blocks) *n_blocks = l->layer.numBlocks();
+  if (bytes) *bytes = l->layer.memorySize();
+  return COX_OK;
+}
+int coxo_layer_download(coxo_layer* l, int32_t* idx, uint32_t* vox, uint64_t cap, uint64_t* n_blocks) {
+  const uint64_t n = l->layer.numBlocks();
+  if (n_blocks) *n_blocks = n;
+  if (cap == 0 && !idx && !vox) return COX_OK;
+  if (cap < n) return COX_ERR_BUFFER_TOO_SMALL;
+  std::map<std::tuple<int, int, int>, const Block*> sorted;  // (z,y,x) order
+  for (auto& kv : l->layer.blocks) sorted[std::make_tuple(kv.first.z, kv.first.y, kv.first.x)] = kv.second.get();
+  const size_t nv = static_cast<size_t>(l->layer.vps) * l->layer.vps * l->layer.vps;
+  uint64_t i = 0;
+  for (auto& kv : sorted) {
+    const Block* b = kv.second;
+    idx[3 * i + 0] = b->index.x;
+    idx[3 * i + 1] = b->index.y;
+    idx[3 * i + 2] = b->index.z;
+    for (size_t v = 0; v < nv; ++v) voxelToWords(b->voxels[v], &vox[(i * nv + v) * 3]);
+    ++i;
+  }
+  return COX_OK;
+}
+int coxo_layer_upload(coxo_layer* l, const int32_t* idx, const uint32_t* vox, uint64_t n, int action) {
+  if (action < 0 || action > 2) return COX_ERR_INVALID_ARG;
+  if (action == 2) l->layer.removeAllBlocks();
+  const size_t nv = static_cast<size_t>(l->layer.vps) * l->layer.vps * l->layer.vps;
+  for (uint64_t i = 0; i < n; ++i) {
+    Block* b = l->layer.allocateBlock(BIdx{idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]});
+    for (size_t v = 0; v < nv; ++v) {
+      TsdfVoxel in;
+      wordsToVoxel(&vox[(i * nv + v) * 3], &in);
+      if (action == 1)
+        mergeVoxelAIntoVoxelB(in, &b->voxels[v]);
+      else
+        b->voxels[v] = in;
+    }
+  }
+  return COX_OK;
+}
+
+int coxo_integrator_create(coxo_layer* l, const cox_tsdf_config* cfg, int method, coxo_integrator** out) {
+  if (!l || !cfg || !out || method < 0 || method > 2) return COX_ERR_INVALID_ARG;
+  auto* h = new coxo_integrator();
+  h->integ.reset(new Integrator(&l->layer, toCfg(cfg), method));
+  *out = h;
+  return COX_OK;
+}
+void coxo_integrator_destroy(coxo_integrator* h) { delete h; }
+int coxo_integrator_set_count_touched(coxo_integrator* h, int on) {
+  h->integ->count_touched = on != 0;
+  return COX_OK;
+}
+int coxo_integrate_points(coxo_integrator* h, const float T[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
+  Transform Tr{T[0], T[1], T[2], T[3], {T[4], T[5], T[6]}};
+  static_assert(sizeof(V3) == 12 && sizeof(Color) == 4, "layout");
+  h->integ->integratePointCloud(Tr, reinterpret_cast<const V3*>(xyz), reinterpret_cast<const Color*>(rgba), n, freespace != 0);
+  return COX_OK;
+}
+int coxo_integrator_sync(coxo_integrator*) { return COX_OK; }
+int coxo_integrator_last_stats(coxo_integrator* h, cox_frame_stats* s) {
+  const FrameStats& f = h->integ->last_stats;
+  s->n_points = f.n_points;
+  s->n_valid = f.n_valid;
+  s->n_rays = f.n_rays;
+  s->n_updates = f.n_updates;
+  s->n_touched_voxels = f.n_touched_voxels;
+  s->n_touched_blocks = 0;
+  s->n_new_blocks = f.n_new_blocks;
+  return COX_OK;
+}
+
+// ---- small probes used by the known-answer tests ----------------------------------------
+int coxo_grid_index(const float p[3], float inv, int64_t out[3]) {
+  const GIdx g = gridIndexFromPoint(V3{p[0], p[1], p[2]}, inv);
+  out[0] = g.x;
+  out[1] = g.y;
+  out[2] = g.z;
+  return COX_OK;
+}
+int coxo_block_local(const int64_t g[3], int vps, int32_t block[3], int32_t local[3], int32_t* linear) {
+  const BIdx b = blockFromGlobal(GIdx{g[0], g[1], g[2]}, 1.0f / static_cast<float>(vps));
+  block[0] = b.x;
+  block[1] = b.y;
+  block[2] = b.z;
+  local[0] = localFromGlobal(g[0], vps);
+  local[1] = localFromGlobal(g[1], vps);
+  local[2] = localFromGlobal(g[2], vps);
+  *linear = linearIndex(local[0], local[1], local[2], vps);
+  return COX_OK;
+}
+// cast one ray; writes up to cap indices (3 int64 each); returns the count via *n
+int coxo_raycast(const float origin[3], const float point_G[3], int is_clearing, int carving, float max_len, float inv, float trunc,
+                 int cast_from_origin, int64_t* out, uint64_t cap, uint64_t* n) {
+  RayCaster rc(V3{origin[0], origin[1], origin[2]}, V3{point_G[0], point_G[1], point_G[2]}, is_clearing != 0, carving != 0, max_len, inv, trunc,
+               cast_from_origin != 0);
+  uint64_t i = 0;
+  GIdx g;
+  while (rc.next(&g)) {
+    if (i < cap) {
+      out[3 * i] = g.x;
+      out[3 * i + 1] = g.y;
+      out[3 * i + 2] = g.z;
+    }
+    ++i;
+  }
+  *n = i;
+  return COX_OK;
+}
+int coxo_transform_point(const float T[7], const float p[3], float out[3]) {
+  Transform Tr{T[0], T[1], T[2], T[3], {T[4], T[5], T[6]}};
+  const V3 r = transform(Tr, V3{p[0], p[1], p[2]});
+  out[0] = r.x;
+  out[1] = r.y;
+  out[2] = r.z;
+  return COX_OK;
+}
+uint64_t coxo_mixed_index(uint64_t seq, uint64_t n) { return mixedIndex(seq, n); }
+// trilinear probe: returns 1 if interpolation possible
+int coxo_interp(coxo_layer* l, const float pos[3], float* value, float grad[3]) {
+  const Interp it = getVoxelsAndQVector(l->layer, V3{pos[0], pos[1], pos[2]});
+  if (!it.ok) return 0;
+  interpValueAndGrad(it, l->layer.voxel_size_inv, value, grad);
+  return 1;
+}
+
+// ---- registration -------------------------------------------------------------------------
+int coxo_regpoints_create(int /*device*/, const float* p, uint64_t n, coxo_regpoints** out) {
+  auto* h = new coxo_regpoints();
+  h->pts.resize(n);
+  std::memcpy(h->pts.data(), p, n * sizeof(RegPoint));
+  *out = h;
+  return COX_OK;
+}
+void coxo_regpoints_destroy(coxo_regpoints* p) { delete p; }
+int coxo_reg_create(const coxo_regpoints* ref, const coxo_layer* reading, const cox_reg_config* cfg, coxo_reg** out) {
+  auto* h = new coxo_reg();
+  h->ref = ref;
+  h->reading = reading;
+  h->cfg.no_correspondence_cost = cfg ? cfg->no_correspondence_cost : 0.0;
+  *out = h;
+  return COX_OK;
+}
+void coxo_reg_destroy(coxo_reg* r) { delete r; }
+
+static int regRun(coxo_reg* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double* residuals,
+                  double* jf, double* jr, double* H, double* b, double* cost, uint64_t* n_corr) {
+  const size_t npts = reg->ref->pts.size();
+  if (!sample_idx && n_res != npts) return COX_ERR_INVALID_ARG;
+  const RelPose P = makeRelPose(pose_ref, pose_read);
+  double sum_w = 0.0;
+  uint64_t nc = 0;
+  double Hs[64] = {0}, bs[8] = {0}, c = 0.0;
+  for (uint64_t i = 0; i < n_res; ++i) {
+    const size_t pi = sample_idx ? sample_idx[i] : i;
+    if (pi >= npts) return COX_ERR_INVALID_ARG;
+    double r, Jf[4], Jr[4];
+    bool has;
+    const float w = regResidual(reg->reading->layer, P, reg->ref->pts[pi], reg->cfg, &r, Jf, Jr, &has);
+    sum_w += static_cast<double>(w);
+    nc += has ? 1 : 0;
+    if (residuals) residuals[i] = r;
+    if (jf)
+      for (int k = 0; k < 4; ++k) jf[4 * i + k] = Jf[k];
+    if (jr)
+      for (int k = 0; k < 4; ++k) jr[4 * i + k] = Jr[k];
+    if (H) {
+      double J[8] = {Jf[0], Jf[1], Jf[2], Jf[3], Jr[0], Jr[1], Jr[2], Jr[3]};
+      for (int a = 0; a < 8; ++a) {
+        for (int bb = 0; bb < 8; ++bb) Hs[8 * a + bb] += J[a] * J[bb];
+        bs[a] += J[a] * r;
+      }
+      c += r * r;
+    }
+  }
+  // "finally scale all by N / sum(w)"
+  const double scale = (sum_w > 0.0) ? static_cast<double>(n_res) / sum_w : 0.0;
+  if (residuals)
+    for (uint64_t i = 0; i < n_res; ++i) residuals[i] *= scale;
+  if (jf)
+    for (uint64_t i = 0; i < 4 * n_res; ++i) jf[i] *= scale;
+  if (jr)
+    for (uint64_t i = 0; i < 4 * n_res; ++i) jr[i] *= scale;
+  if (H) {
+    for (int i = 0; i < 64; ++i) H[i] = Hs[i] * scale * scale;
+    for (int i = 0; i < 8; ++i) b[i] = bs[i] * scale * scale;
+    *cost = 0.5 * c * scale * scale;
+  }
+  if (n_corr) *n_corr = nc;
+  return COX_OK;
+}
+int coxo_reg_evaluate(coxo_reg* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res,
+                      double* residuals, double* jac_ref, double* jac_read) {
+  return regRun(reg, pose_ref, pose_read, sample_idx, n_res, residuals, jac_ref, jac_read, nullptr, nullptr, nullptr, nullptr);
+}
+int coxo_reg_normal_eq(coxo_reg* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double H[64],
+                       double b[8], double* cost, uint64_t* n_corr) {
+  return regRun(reg, pose_ref, pose_read, sample_idx, n_res, nullptr, nullptr, nullptr, H, b, cost, n_corr);
+}
+
+}  // extern "C"
