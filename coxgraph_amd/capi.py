@@ -191,6 +191,9 @@ class Integrator:
         self.eng.check(self.eng.fn("integrator_last_stats")(self.h, C.byref(s)), "integrator_last_stats")
         return s.asdict()
 
+    def set_profiling(self, on=True):
+        self.eng.check(self.eng.fn("integrator_set_profiling")(self.h, C.c_int(int(on))), "integrator_set_profiling")
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         self.eng.check(self.eng.fn("integrator_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))),

@@ -1,0 +1,22 @@
+// Private host-side definitions shared by the translation units of libcoxgraph_hip.so.
+#pragma once
+#include "cox_device.hpp"
+
+using cox::u32;
+using cox::u64;
+
+struct cox_layer {
+  int device = 0;
+  float voxel_size = 0, voxel_size_inv = 0, block_size = 0, block_size_inv = 0;
+  u64 capacity = 0;        // pool blocks
+  u32 ht_cap = 0;          // hash slots (power of two)
+  u32* voxels = nullptr;   // [capacity][4096][3] wire words
+  u64* ht_keys = nullptr;  // [ht_cap] packed block index, kEmptyKey when free
+  u32* ht_vals = nullptr;  // [ht_cap] pool index
+  u32* ht_stamp = nullptr; // [ht_cap] last frame id that touched the block
+  u32* ht_ord = nullptr;   // [ht_cap] dense ordinal of the block within that frame
+  u64* block_keys = nullptr;  // [capacity] key of pool block i
+  u32* d_nblocks = nullptr;   // device counter
+  u32* d_err = nullptr;       // sticky device error bits
+  u32 frame_id = 0;           // shared by every integrator on this layer
+};

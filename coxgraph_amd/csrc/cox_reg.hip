@@ -1,0 +1,501 @@
+// MI355X (gfx950) submap TSDF-to-TSDF registration cost behind include/coxgraph_hip.h.
+//
+// Replaces the work of voxgraph's RegistrationCostFunction::Evaluate for the constraint that
+// coxgraph::server::PoseGraphInterface::addForceRegistrationConstraint requests
+// (coxgraph/src/server/pose_graph_interface.cpp:88-105) and that PoseGraphInterface::optimize
+// evaluates inside ceres::Solve (pose_graph_interface.cpp:32-49).
+//
+//   cox_reg_evaluate   Ceres-shaped: residuals[n], two row-major n x 4 Jacobians
+//   cox_reg_normal_eq  fused: per-point residual + Jacobian rows stay in registers / LDS; each wave
+//                      accumulates sum x x^T for x = [J_ref(4) J_read(4) r 1 w has_corr] with
+//                      v_mfma_f64_16x16x4_f64 (the only MFMA use in the engine), partials are summed
+//                      in a fixed order, so H, b, cost are reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <new>
+
+#include "../../include/coxgraph_hip.h"
+#include "cox_device.hpp"
+#include "cox_internal.hpp"
+
+using namespace cox;
+
+#define COX_HIP(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) {                            \
+      fprintf(stderr, "[coxgraph_hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return (e_ == hipErrorOutOfMemory) ? COX_ERR_OUT_OF_MEMORY : COX_ERR_NO_DEVICE; \
+    }                                                  \
+  } while (0)
+
+
+struct ReadingView {
+  const u32* voxels;
+  const u64* ht_keys;
+  const u32* ht_vals;
+  u32 ht_mask;
+  float voxel_size, voxel_size_inv, block_size, block_size_inv;
+};
+
+// relative pose reading<-reference: float for the per-point transform, double for the Jacobians
+struct RelPose {
+  float R[9];
+  float t[3];
+  double cf, sf, cr, sr;
+  double tf[3], tr[3];
+};
+
+static RelPose make_rel_pose(const double ref[4], const double read[4]) {
+  RelPose P;
+  P.cf = std::cos(ref[3]);
+  P.sf = std::sin(ref[3]);
+  P.cr = std::cos(read[3]);
+  P.sr = std::sin(read[3]);
+  for (int k = 0; k < 3; ++k) {
+    P.tf[k] = ref[k];
+    P.tr[k] = read[k];
+  }
+  const double c = P.cr * P.cf + P.sr * P.sf, s = P.cr * P.sf - P.sr * P.cf;
+  const double Rd[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) P.R[i] = static_cast<float>(Rd[i]);
+  const double dx = ref[0] - read[0], dy = ref[1] - read[1], dz = ref[2] - read[2];
+  P.t[0] = static_cast<float>(P.cr * dx + P.sr * dy);
+  P.t[1] = static_cast<float>(-P.sr * dx + P.cr * dy);
+  P.t[2] = static_cast<float>(dz);
+  return P;
+}
+
+__constant__ float c_interp_table[8][8] = {{1, 0, 0, 0, 0, 0, 0, 0},   {-1, 0, 0, 0, 1, 0, 0, 0},   {-1, 0, 1, 0, 0, 0, 0, 0},
+                                           {-1, 1, 0, 0, 0, 0, 0, 0},  {1, 0, -1, 0, -1, 0, 1, 0},  {1, -1, -1, 1, 0, 0, 0, 0},
+                                           {1, -1, 0, 0, -1, 1, 0, 0}, {-1, 1, 1, -1, 1, -1, -1, 1}};
+
+struct PointResult {
+  double r;
+  double J[8];  // J_ref(4), J_read(4), unscaled
+  float w;
+  bool has;
+};
+
+// voxblox Interpolator<TsdfVoxel>::getVoxelsAndQVector + trilinear value/gradient, then the voxgraph residual
+__device__ __forceinline__ PointResult reg_point(const ReadingView& L, const RelPose& P, const float* __restrict__ pt, double no_corr_cost) {
+  PointResult o;
+  const float px = pt[0], py = pt[1], pz = pt[2], pd = pt[3], pw = pt[4];
+  o.w = pw;
+  o.has = false;
+  o.r = static_cast<double>(pw) * no_corr_cost;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o.J[k] = 0.0;
+  const float pos[3] = {(P.R[0] * px + P.R[1] * py) + P.R[2] * pz + P.t[0], (P.R[3] * px + P.R[4] * py) + P.R[5] * pz + P.t[1],
+                        (P.R[6] * px + P.R[7] * py) + P.R[8] * pz + P.t[2]};
+  float sc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sc[k] = pos[k] * L.block_size_inv;
+  if (!(index_in_range(sc[0]) && index_in_range(sc[1]) && index_in_range(sc[2]))) return o;
+  int b[3], vi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b[k] = grid_index(sc[k]);
+  if (ht_find(L.ht_keys, L.ht_mask, pack_key(b[0], b[1], b[2])) == kInvalid) return o;  // block of the point must exist
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float origin = static_cast<float>(b[k]) * L.block_size;
+    const float rel = pos[k] - origin;
+    int v = grid_index(rel * L.voxel_size_inv);
+    v = v > 15 ? 15 : (v < 0 ? 0 : v);
+    const float c = origin + center_coord(v, L.voxel_size);
+    if (pos[k] - c < 0.0f) {
+      v--;
+      if (v < 0) {
+        b[k]--;
+        v += 16;
+      }
+    }
+    vi[k] = v;
+  }
+  const u32 base_slot = ht_find(L.ht_keys, L.ht_mask, pack_key(b[0], b[1], b[2]));
+  if (base_slot == kInvalid) return o;
+  const u32 base_pool = L.ht_vals[base_slot];
+  if (base_pool == kInvalid) return o;
+  float d[8], off[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float c0 = static_cast<float>(b[k]) * L.block_size + center_coord(vi[k], L.voxel_size);
+    off[k] = (pos[k] - c0) * L.voxel_size_inv;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int v[3] = {vi[0] + ((i >> 2) & 1), vi[1] + ((i >> 1) & 1), vi[2] + (i & 1)};
+    int nb[3] = {b[0], b[1], b[2]};
+    bool moved = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (v[k] >= 16) {
+        nb[k]++;
+        v[k] -= 16;
+        moved = true;
+      }
+    u32 pool = base_pool;
+    if (moved) {
+      const u32 slot = ht_find(L.ht_keys, L.ht_mask, pack_key(nb[0], nb[1], nb[2]));
+      if (slot == kInvalid) return o;
+      pool = L.ht_vals[slot];
+      if (pool == kInvalid) return o;
+    }
+    const u32* vox = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + static_cast<u32>(v[0] + 16 * (v[1] + 16 * v[2]))) * kWordsPerVoxel;
+    d[i] = __uint_as_float(vox[0]);
+    const float w = __uint_as_float(vox[1]);
+    if (!(w > 0.0f)) return o;  // Interpolator<TsdfVoxel>::isVoxelValid
+  }
+  float md[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += c_interp_table[r][c] * d[c];
+    md[r] = s;
+  }
+  const float dx = off[0], dy = off[1], dz = off[2];
+  const float q[8] = {1.0f, dx, dy, dz, dx * dy, dy * dz, dz * dx, dx * dy * dz};
+  const float qx[8] = {0, 1, 0, 0, dy, 0, dz, dy * dz};
+  const float qy[8] = {0, 0, 1, 0, dx, dz, 0, dz * dx};
+  const float qz[8] = {0, 0, 0, 1, 0, dy, dx, dx * dy};
+  float val = 0.0f, gxf = 0.0f, gyf = 0.0f, gzf = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) val += q[i] * md[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    gxf += qx[i] * md[i];
+    gyf += qy[i] * md[i];
+    gzf += qz[i] * md[i];
+  }
+  gxf *= L.voxel_size_inv;
+  gyf *= L.voxel_size_inv;
+  gzf *= L.voxel_size_inv;
+  o.has = true;
+  o.r = static_cast<double>((pd - val) * pw);
+  const double w = pw, gx = gxf, gy = gyf, gz = gzf;
+  const double gRx = gx * P.cr - gy * P.sr, gRy = gx * P.sr + gy * P.cr, gRz = gz;
+  const double dRfp_x = -P.sf * px - P.cf * py, dRfp_y = P.cf * px - P.sf * py;
+  const double qxx = (P.cf * px - P.sf * py) + P.tf[0] - P.tr[0], qyy = (P.sf * px + P.cf * py) + P.tf[1] - P.tr[1];
+  const double dpr_x = -P.sr * qxx + P.cr * qyy, dpr_y = -P.cr * qxx - P.sr * qyy;
+  o.J[0] = -w * gRx;
+  o.J[1] = -w * gRy;
+  o.J[2] = -w * gRz;
+  o.J[3] = -w * (gRx * dRfp_x + gRy * dRfp_y);
+  o.J[4] = w * gRx;
+  o.J[5] = w * gRy;
+  o.J[6] = w * gRz;
+  o.J[7] = -w * (gx * dpr_x + gy * dpr_y);
+  return o;
+}
+
+// ---- Ceres-shaped evaluation ------------------------------------------------------------------------
+constexpr int kRegThreads = 256;
+constexpr int kPartial = 256;  // one 16x16 f64 tile per workgroup
+
+__global__ void __launch_bounds__(kRegThreads) k_reg_evaluate(ReadingView L, RelPose P, const float* __restrict__ pts, const u32* __restrict__ sample_idx,
+                                                              u32 n_res, double no_corr_cost, double* __restrict__ res, double* __restrict__ jf,
+                                                              double* __restrict__ jr, double* __restrict__ block_w) {
+  __shared__ double wsum[kRegThreads / 64];
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  double w = 0.0;
+  if (i < n_res) {
+    const u32 pi = sample_idx ? sample_idx[i] : i;
+    const PointResult o = reg_point(L, P, pts + 5ull * pi, no_corr_cost);
+    w = static_cast<double>(o.w);
+    if (res) res[i] = o.r;
+    if (jf) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) jf[4ull * i + k] = o.J[k];
+    }
+    if (jr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) jr[4ull * i + k] = o.J[4 + k];
+    }
+  }
+  // deterministic sum of the reference weights: lanes in order, waves in order, blocks on the host side
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) block_w[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+__global__ void k_reg_sum_blocks(const double* __restrict__ block_w, u32 nb, u32 n_res, double* __restrict__ scale_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (u32 b = 0; b < nb; ++b) s += block_w[b];
+    scale_out[0] = s > 0.0 ? static_cast<double>(n_res) / s : 0.0;
+    scale_out[1] = s;
+  }
+}
+__global__ void __launch_bounds__(256) k_reg_scale(double* __restrict__ a, size_t n, const double* __restrict__ scale) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= scale[0];
+}
+
+// ---- fused normal equations ----------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, RelPose P, const float* __restrict__ pts, const u32* __restrict__ sample_idx,
+                                                               u32 n_res, double no_corr_cost, double* __restrict__ partials /*[grid][256]*/) {
+  __shared__ double X[kRegThreads / 64][16][68];  // per wave: 16 components x 64 points (rows padded to 68: conflict-free writes, 2-way reads)
+  __shared__ double tile[kRegThreads / 64][256];
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const u32 stride = gridDim.x * blockDim.x;
+  const u32 n_iter = (n_res + stride - 1) / stride;
+  for (u32 it = 0; it < n_iter; ++it) {
+    const u32 i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = 0.0;
+    if (i < n_res) {
+      const u32 pi = sample_idx ? sample_idx[i] : i;
+      const PointResult o = reg_point(L, P, pts + 5ull * pi, no_corr_cost);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = o.J[k];
+      x[8] = o.r;
+      x[9] = 1.0;
+      x[10] = static_cast<double>(o.w);
+      x[11] = o.has ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[wave][k][lane] = x[k];
+    __builtin_amdgcn_wave_barrier();
+    // sum_p x_p x_p^T over this wave's 64 points: 16 MFMA steps of K = 4 points each.
+    // f64 16x16x4 operand map: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15].
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const double a = X[wave][lane & 15u][4 * t + (lane >> 4)];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][((lane >> 4) + 4 * r) * 16 + (lane & 15u)] = acc[r];
+  __syncthreads();
+  partials[static_cast<size_t>(blockIdx.x) * kPartial + threadIdx.x] =
+      ((tile[0][threadIdx.x] + tile[1][threadIdx.x]) + tile[2][threadIdx.x]) + tile[3][threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_reg_reduce_partials(const double* __restrict__ partials, u32 nb, double* __restrict__ out /*[256]*/) {
+  double s = 0.0;
+  for (u32 b = 0; b < nb; ++b) s += partials[static_cast<size_t>(b) * kPartial + threadIdx.x];
+  out[threadIdx.x] = s;
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------
+struct cox_regpoints {
+  int device = 0;
+  float* pts = nullptr;
+  u64 n = 0;
+};
+struct cox_reg {
+  const cox_regpoints* ref = nullptr;
+  const cox_layer* reading = nullptr;
+  double no_corr_cost = 0.0;
+  hipStream_t stream = nullptr;
+  u32* d_idx = nullptr;
+  u64 idx_cap = 0;
+  double *d_res = nullptr, *d_jf = nullptr, *d_jr = nullptr;
+  u64 res_cap = 0, jf_cap = 0, jr_cap = 0;
+  double* d_small = nullptr;  // block sums / partials / results
+  u64 small_cap = 0;
+  double* h_small = nullptr;  // pinned, 256 + 2 doubles
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double ms = 0.0;
+  uint64_t launches = 0;
+};
+
+template <typename T>
+static int dev_grow(T** p, u64* cap, u64 need) {
+  if (need <= *cap) return COX_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), need * sizeof(T));
+  if (e != hipSuccess) return (e == hipErrorOutOfMemory) ? COX_ERR_OUT_OF_MEMORY : COX_ERR_NO_DEVICE;
+  *cap = need;
+  return COX_OK;
+}
+#define COX_TRY(expr)              \
+  do {                             \
+    int st_ = (expr);              \
+    if (st_ != COX_OK) return st_; \
+  } while (0)
+
+static ReadingView reading_view(const cox_layer* L) {
+  return ReadingView{L->voxels, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->voxel_size, L->voxel_size_inv, L->block_size, L->block_size_inv};
+}
+
+static int stage_samples(cox_reg* G, const uint32_t* sample_idx, uint64_t n_res, const u32** d_idx_out) {
+  *d_idx_out = nullptr;
+  if (!sample_idx) return (n_res == G->ref->n) ? COX_OK : COX_ERR_INVALID_ARG;
+  for (uint64_t i = 0; i < n_res; ++i)
+    if (sample_idx[i] >= G->ref->n) return COX_ERR_INVALID_ARG;
+  COX_TRY(dev_grow(&G->d_idx, &G->idx_cap, n_res));
+  COX_HIP(hipMemcpyAsync(G->d_idx, sample_idx, sizeof(u32) * n_res, hipMemcpyHostToDevice, G->stream));
+  *d_idx_out = G->d_idx;
+  return COX_OK;
+}
+
+extern "C" {
+
+int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, cox_regpoints_t** out) {
+  if (!out || (n && !xyz_dist_weight) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return COX_ERR_NO_DEVICE;
+  COX_HIP(hipSetDevice(device));
+  cox_regpoints* R = new (std::nothrow) cox_regpoints();
+  if (!R) return COX_ERR_OUT_OF_MEMORY;
+  R->device = device;
+  R->n = n;
+  if (n) {
+    if (hipMalloc(reinterpret_cast<void**>(&R->pts), sizeof(float) * 5 * n) != hipSuccess) {
+      delete R;
+      return COX_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemcpy(R->pts, xyz_dist_weight, sizeof(float) * 5 * n, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(R->pts);
+      delete R;
+      return COX_ERR_NO_DEVICE;
+    }
+  }
+  *out = R;
+  return COX_OK;
+}
+void cox_regpoints_destroy(cox_regpoints_t* R) {
+  if (!R) return;
+  (void)hipSetDevice(R->device);
+  if (R->pts) (void)hipFree(R->pts);
+  delete R;
+}
+
+int cox_reg_create(const cox_regpoints_t* reference, const cox_layer_t* reading, const cox_reg_config* cfg, cox_reg_t** out) {
+  if (!reference || !reading || !out) return COX_ERR_INVALID_ARG;
+  const cox_layer* L = reinterpret_cast<const cox_layer*>(reading);
+  if (L->device != reference->device) return COX_ERR_INVALID_ARG;  // exchange submaps first
+  COX_HIP(hipSetDevice(L->device));
+  cox_reg* G = new (std::nothrow) cox_reg();
+  if (!G) return COX_ERR_OUT_OF_MEMORY;
+  G->ref = reference;
+  G->reading = L;
+  G->no_corr_cost = cfg ? cfg->no_correspondence_cost : 0.0;
+  bool ok = hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&G->h_small), sizeof(double) * 258, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipEventCreate(&G->ev0) == hipSuccess && hipEventCreate(&G->ev1) == hipSuccess;
+  if (!ok) {
+    cox_reg_destroy(G);
+    return COX_ERR_NO_DEVICE;
+  }
+  *out = G;
+  return COX_OK;
+}
+void cox_reg_destroy(cox_reg_t* G) {
+  if (!G) return;
+  (void)hipSetDevice(G->reading->device);
+  if (G->stream) (void)hipStreamSynchronize(G->stream);
+  void* ptrs[] = {G->d_idx, G->d_res, G->d_jf, G->d_jr, G->d_small};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (G->h_small) (void)hipHostFree(G->h_small);
+  if (G->ev0) (void)hipEventDestroy(G->ev0);
+  if (G->ev1) (void)hipEventDestroy(G->ev1);
+  if (G->stream) (void)hipStreamDestroy(G->stream);
+  delete G;
+}
+
+int cox_reg_evaluate(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double* residuals,
+                     double* jac_ref, double* jac_read) {
+  if (!G || !pose_ref || !pose_read || n_res > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(G->reading->device));
+  if (n_res == 0) return sample_idx || G->ref->n == 0 ? COX_OK : COX_ERR_INVALID_ARG;
+  const u32* d_idx;
+  COX_TRY(stage_samples(G, sample_idx, n_res, &d_idx));
+  const u32 n = static_cast<u32>(n_res);
+  const u32 nb = (n + kRegThreads - 1) / kRegThreads;
+  COX_TRY(dev_grow(&G->d_res, &G->res_cap, n_res));
+  COX_TRY(dev_grow(&G->d_jf, &G->jf_cap, 4 * n_res));
+  COX_TRY(dev_grow(&G->d_jr, &G->jr_cap, 4 * n_res));
+  COX_TRY(dev_grow(&G->d_small, &G->small_cap, static_cast<u64>(nb) + 2));
+  const RelPose P = make_rel_pose(pose_ref, pose_read);
+  hipStream_t s = G->stream;
+  COX_HIP(hipEventRecord(G->ev0, s));
+  hipLaunchKernelGGL(k_reg_evaluate, dim3(nb), dim3(kRegThreads), 0, s, reading_view(G->reading), P, G->ref->pts, d_idx, n, G->no_corr_cost,
+                     residuals ? G->d_res : nullptr, jac_ref ? G->d_jf : nullptr, jac_read ? G->d_jr : nullptr, G->d_small + 2);
+  hipLaunchKernelGGL(k_reg_sum_blocks, dim3(1), dim3(64), 0, s, G->d_small + 2, nb, n, G->d_small);
+  if (residuals) hipLaunchKernelGGL(k_reg_scale, dim3((n + 255) / 256), dim3(256), 0, s, G->d_res, static_cast<size_t>(n), G->d_small);
+  if (jac_ref) hipLaunchKernelGGL(k_reg_scale, dim3((4 * n + 255) / 256), dim3(256), 0, s, G->d_jf, static_cast<size_t>(4) * n, G->d_small);
+  if (jac_read) hipLaunchKernelGGL(k_reg_scale, dim3((4 * n + 255) / 256), dim3(256), 0, s, G->d_jr, static_cast<size_t>(4) * n, G->d_small);
+  COX_HIP(hipEventRecord(G->ev1, s));
+  if (residuals) COX_HIP(hipMemcpyAsync(residuals, G->d_res, sizeof(double) * n_res, hipMemcpyDeviceToHost, s));
+  if (jac_ref) COX_HIP(hipMemcpyAsync(jac_ref, G->d_jf, sizeof(double) * 4 * n_res, hipMemcpyDeviceToHost, s));
+  if (jac_read) COX_HIP(hipMemcpyAsync(jac_read, G->d_jr, sizeof(double) * 4 * n_res, hipMemcpyDeviceToHost, s));
+  COX_HIP(hipStreamSynchronize(s));
+  COX_HIP(hipGetLastError());
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, G->ev0, G->ev1) == hipSuccess) {
+    G->ms += ms;
+    G->launches += 1;
+  }
+  return COX_OK;
+}
+
+int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double H[64],
+                      double b[8], double* cost, uint64_t* n_corr) {
+  if (!G || !pose_ref || !pose_read || !H || !b || !cost || n_res > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(G->reading->device));
+  for (int i = 0; i < 64; ++i) H[i] = 0.0;
+  for (int i = 0; i < 8; ++i) b[i] = 0.0;
+  *cost = 0.0;
+  if (n_corr) *n_corr = 0;
+  if (n_res == 0) return sample_idx || G->ref->n == 0 ? COX_OK : COX_ERR_INVALID_ARG;
+  const u32* d_idx;
+  COX_TRY(stage_samples(G, sample_idx, n_res, &d_idx));
+  const u32 n = static_cast<u32>(n_res);
+  // enough workgroups to fill 256 CUs a few times over, but no more than the work needs
+  const u32 nb = std::min<u32>(1024, (n + kRegThreads - 1) / kRegThreads);
+  COX_TRY(dev_grow(&G->d_small, &G->small_cap, static_cast<u64>(nb) * kPartial + kPartial));
+  const RelPose P = make_rel_pose(pose_ref, pose_read);
+  hipStream_t s = G->stream;
+  COX_HIP(hipEventRecord(G->ev0, s));
+  hipLaunchKernelGGL(k_reg_normal_eq, dim3(nb), dim3(kRegThreads), 0, s, reading_view(G->reading), P, G->ref->pts, d_idx, n, G->no_corr_cost,
+                     G->d_small + kPartial);
+  hipLaunchKernelGGL(k_reg_reduce_partials, dim3(1), dim3(256), 0, s, G->d_small + kPartial, nb, G->d_small);
+  COX_HIP(hipEventRecord(G->ev1, s));
+  COX_HIP(hipMemcpyAsync(G->h_small, G->d_small, sizeof(double) * kPartial, hipMemcpyDeviceToHost, s));
+  COX_HIP(hipStreamSynchronize(s));
+  COX_HIP(hipGetLastError());
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, G->ev0, G->ev1) == hipSuccess) {
+    G->ms += ms;
+    G->launches += 1;
+  }
+  const double* D = G->h_small;  // D[row * 16 + col] = sum_p x[row] x[col]
+  const double sum_w = D[9 * 16 + 10];
+  const double scale = sum_w > 0.0 ? static_cast<double>(n_res) / sum_w : 0.0;
+  const double s2 = scale * scale;
+  for (int r = 0; r < 8; ++r) {
+    for (int c = 0; c < 8; ++c) H[8 * r + c] = D[r * 16 + c] * s2;
+    b[r] = D[r * 16 + 8] * s2;
+  }
+  *cost = 0.5 * D[8 * 16 + 8] * s2;
+  if (n_corr) *n_corr = static_cast<uint64_t>(D[9 * 16 + 11] + 0.5);
+  return COX_OK;
+}
+
+int cox_reg_kernel_time(cox_reg_t* G, double* ms, uint64_t* launches, int reset) {
+  if (!G) return COX_ERR_INVALID_ARG;
+  if (ms) *ms = G->ms;
+  if (launches) *launches = G->launches;
+  if (reset) {
+    G->ms = 0.0;
+    G->launches = 0;
+  }
+  return COX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+"""Parity tests proper: the HIP TSDF engine against the CPU oracle, both through the C ABI.
+
+Bar (north_star): voxel / block indices bit-exact, distances and weights within 1e-4.  The engine applies
+updates to every voxel in the oracle's single-threaded order, so the tests also report (and for the
+configurations below require) bit-identical distance and weight words.
+"""
+import numpy as np
+import pytest
+
+from coxgraph_amd import synth
+from coxgraph_amd.capi import Layer, Integrator, CoxError, words_to_fields
+from util import run_frames, compare_layers, compare_stats, TOL
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
+
+
+def _both(hip, oracle, **kw):
+    la, ia, sa = run_frames(hip, **kw)
+    lb, ib, sb = run_frames(oracle, **kw)
+    return (la, ia, sa), (lb, ib, sb)
+
+
+def test_single_ray_known_answer(hip, oracle):
+    """Same hand-checkable ray as tests/test_oracle_kat.py::test_single_generic_ray_simple_integrator_values."""
+    out = []
+    for eng in (hip, oracle):
+        cfg = eng.default_config(default_truncation_distance=0.3, use_const_weight=1, min_ray_length_m=0.1, max_ray_length_m=5.0)
+        layer = Layer(eng, 0.1, capacity_blocks=256)
+        integ = Integrator(eng, layer, cfg, "simple")
+        T = IDENT.copy()
+        T[4:] = (0.05, 0.07, 0.03)
+        integ.integrate_points(T, np.array([[0.98, 0.34, 0.19]], np.float32), np.array([[10, 20, 30, 255]], np.uint8))
+        out.append((layer, integ.last_stats()))
+    rep = compare_layers(out[0][0], out[1][0])
+    compare_stats([out[0][1]], [out[1][1]])
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0
+
+
+def test_axis_aligned_ray_quirk_matches(hip, oracle):
+    """ray.y == ray.z == 0: the -inf / NaN DDA quirk of the reference must be reproduced by the kernel."""
+    out = []
+    for eng in (hip, oracle):
+        cfg = eng.default_config(default_truncation_distance=0.3, use_const_weight=1, min_ray_length_m=0.1, max_ray_length_m=5.0)
+        layer = Layer(eng, 0.1, capacity_blocks=256)
+        integ = Integrator(eng, layer, cfg, "simple")
+        T = IDENT.copy()
+        T[4:] = (0.05, 0.05, 0.05)
+        integ.integrate_points(T, np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]], np.float32), None)
+        out.append((layer, integ.last_stats()))
+    rep = compare_layers(out[0][0], out[1][0])
+    compare_stats([out[0][1]], [out[1][1]])
+    assert rep["bitexact_d"] and rep["bitexact_w"]
+
+
+@pytest.mark.parametrize("method", ["merged", "simple"])
+@pytest.mark.parametrize("voxel", [0.10, 0.05])
+def test_subsampled_frames_parity(hip, oracle, method, voxel):
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method=method, voxel=voxel, frames=[0, 1, 2, 40], subsample=7, capacity_blocks=4096)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(method, voxel, rep)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+@pytest.mark.parametrize("method,voxel", [("merged", 0.05), ("merged", 0.10), ("simple", 0.10)])
+def test_full_frames_parity(hip, oracle, method, voxel):
+    """BASELINE configs[0]/[1] input shape: full 640x480 frames (307 200 points each)."""
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method=method, voxel=voxel, frames=[0, 1, 2], capacity_blocks=8192)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(method, voxel, rep, sa[-1])
+    assert rep["n_diff_w"] == 0 and rep["err_d"] <= TOL
+
+
+def test_simple_full_frame_5cm_parity(hip, oracle):
+    """Heaviest semantics at the headline resolution: ~2.5e7 (ray, voxel) updates in one frame."""
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="simple", voxel=0.05, frames=[3], capacity_blocks=8192)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(rep, sa)
+    assert rep["err_d"] <= TOL and rep["n_diff_w"] == 0
+
+
+def test_fine_voxels_2cm(hip, oracle):
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.02, frames=[0, 5], subsample=3, capacity_blocks=40000)
+    compare_stats(sa, sb)
+    print(compare_layers(la, lb))
+
+
+@pytest.mark.parametrize("overrides", [
+    dict(use_const_weight=0),                                        # 1/z^2 weights
+    dict(voxel_carving_enabled=0),                                   # rays start trunc in front of the surface
+    dict(use_weight_dropoff=0),
+    dict(use_sparsity_compensation_factor=1, sparsity_compensation_factor=20.0, max_weight=1000.0),  # coxgraph_client.yaml:58,64-66
+    dict(max_ray_length_m=2.5),                                      # many clearing rays
+    dict(max_ray_length_m=2.5, allow_clear=0),                       # ... which are then dropped instead
+    dict(enable_anti_grazing=1),
+    dict(max_weight=3.0),                                            # weight saturation inside the sequence
+])
+def test_config_variants(hip, oracle, overrides):
+    for method in ("merged", "simple"):
+        if method == "simple" and "enable_anti_grazing" in overrides:
+            continue
+        (la, _, sa), (lb, _, sb) = _both(hip, oracle, method=method, voxel=0.10, frames=[0, 1, 2, 3], subsample=5, capacity_blocks=4096,
+                                          cfg_overrides=overrides)
+        compare_stats(sa, sb)
+        rep = compare_layers(la, lb)
+        print(method, overrides, rep)
+
+
+def test_nan_and_noise_inputs(hip, oracle):
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.05, frames=[0, 1], subsample=3, capacity_blocks=8192,
+                                      nan_fraction=0.02, noise=True)
+    compare_stats(sa, sb)
+    compare_layers(la, lb)
+
+
+def test_freespace_points_and_ragged_inputs(hip, oracle):
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 63, 64, 65, 1023, 1024, 1025, 5000):
+        pts = (rng.uniform(-1, 1, (n, 3)) * np.array([3.0, 2.0, 3.0]) + np.array([0, 0, 3.5])).astype(np.float32)
+        rgba = rng.integers(0, 256, (n, 4)).astype(np.uint8)
+        out = []
+        for eng in (hip, oracle):
+            cfg = eng.default_config(**synth.integrator_overrides(0.10))
+            layer = Layer(eng, 0.10, capacity_blocks=4096)
+            integ = Integrator(eng, layer, cfg, "merged")
+            T = np.array([0.9238795, 0.0, 0.3826834, 0.0, 0.3, -0.2, 1.0], np.float32)
+            integ.integrate_points(T, pts, rgba, freespace=(n % 2 == 1))
+            integ.integrate_points(T, pts[: n // 2], None)
+            out.append((layer, integ.last_stats()))
+        compare_layers(out[0][0], out[1][0])
+        compare_stats([out[0][1]], [out[1][1]])
+
+
+def test_all_points_invalid_allocates_nothing(hip):
+    cfg = hip.default_config(**synth.integrator_overrides(0.05))
+    layer = Layer(hip, 0.05, capacity_blocks=64)
+    integ = Integrator(hip, layer, cfg, "merged")
+    pts = np.full((1000, 3), 0.01, np.float32)  # closer than min_ray_length_m
+    integ.integrate_points(IDENT, pts, None)
+    st = integ.last_stats()
+    assert st["n_valid"] == 0 and st["n_rays"] == 0 and st["n_updates"] == 0 and layer.stats()[0] == 0
+
+
+def test_pool_exhaustion_is_reported(hip):
+    cfg = hip.default_config(**synth.integrator_overrides(0.05))
+    layer = Layer(hip, 0.05, capacity_blocks=8)
+    integ = Integrator(hip, layer, cfg, "merged")
+    T, pts, rgba, _ = synth.make_frame(0)
+    with pytest.raises(CoxError) as e:
+        integ.integrate_points(T, pts[::4], rgba[::4])
+    assert e.value.status == -4
+
+
+def test_fast_method_and_sorted_order_are_refused_loudly(hip):
+    layer = Layer(hip, 0.05, capacity_blocks=64)
+    with pytest.raises(CoxError) as e:
+        Integrator(hip, layer, hip.default_config(), "fast")
+    assert e.value.status == -6
+    with pytest.raises(CoxError):
+        Integrator(hip, layer, hip.default_config(integration_order_mode=1), "merged")
+
+
+def test_layer_wire_roundtrip_merge_clear(hip, oracle):
+    la, _, _ = run_frames(hip, method="merged", voxel=0.10, frames=[0], subsample=9, capacity_blocks=2048)
+    idx, vox = la.download()
+    assert la.stats() == (len(idx), len(idx) * 49152)
+    # oracle deserialises what the engine serialised, and vice versa, identically
+    lo = Layer(oracle, 0.10)
+    lo.upload(idx, vox)
+    i2, v2 = lo.download()
+    assert np.array_equal(idx, i2) and np.array_equal(vox, v2)
+    lh = Layer(hip, 0.10, capacity_blocks=2048)
+    lh.upload(idx[::-1].copy(), vox[::-1].copy())  # arbitrary block order in the message
+    i3, v3 = lh.download()
+    assert np.array_equal(idx, i3) and np.array_equal(vox, v3)
+    # merge action == mergeVoxelAIntoVoxelB on both sides
+    lh.upload(idx, vox, action=1)
+    lo.upload(idx, vox, action=1)
+    rep = compare_layers(lh, lo)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0
+    # reset action and removeAllBlocks
+    lh.upload(idx[:3], vox[:3], action=2)
+    assert lh.stats()[0] == 3
+    lh.clear()
+    assert lh.stats() == (0, 0)
+    # a cleared layer integrates like a new one
+    cfg = hip.default_config(**synth.integrator_overrides(0.10))
+    T, pts, rgba, _ = synth.make_frame(0)
+    Integrator(hip, lh, cfg, "merged").integrate_points(T, pts[::9], rgba[::9])
+    compare_layers(lh, la)
+
+
+def test_depth_front_end_matches_point_path(hip):
+    import torch
+    T, pts, rgba, depth = synth.make_frame(2, nan_fraction=0.02)
+    cfg = hip.default_config(**synth.integrator_overrides(0.05))
+    l1 = Layer(hip, 0.05, capacity_blocks=8192)
+    l2 = Layer(hip, 0.05, capacity_blocks=8192)
+    Integrator(hip, l1, cfg, "merged").integrate_points(T, pts, rgba)
+    d = torch.from_numpy(depth).cuda()
+    c = torch.from_numpy(synth.frame_colors()).cuda()
+    i2 = Integrator(hip, l2, cfg, "merged")
+    i2.integrate_depth_dev(T, d.data_ptr(), c.data_ptr(), 640, 480, synth.INTRINSICS[(640, 480)])
+    i2.sync()
+    rep = compare_layers(l2, l1)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0
+
+
+def test_results_are_reproducible_run_to_run(hip):
+    a, _, _ = run_frames(hip, method="merged", voxel=0.05, frames=[0, 1, 2], capacity_blocks=8192)
+    b, _, _ = run_frames(hip, method="merged", voxel=0.05, frames=[0, 1, 2], capacity_blocks=8192)
+    ia, va = a.download()
+    ib, vb = b.download()
+    assert np.array_equal(ia, ib) and np.array_equal(va, vb)

@@ -1,0 +1,126 @@
+"""Parity of the HIP registration cost (K4) against the CPU oracle, through the C ABI.
+
+Bar: same explicit sample indices, f32 interpolation, f64 outputs; residual
+vector within 1e-4 abs, Jacobians within 1e-3 rel, reduced H / b / cost within 1e-6 rel.
+"""
+import numpy as np
+import pytest
+
+from coxgraph_amd import synth
+from coxgraph_amd.capi import Layer, RegPoints, Registration, words_to_fields
+from util import run_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def registration_points(layer, trunc, min_weight=1.0):
+    """voxgraph 'implicit_to_implicit' point set: voxel centres with weight > min_weight and |d| < trunc,
+    in (z,y,x) block order / linear voxel order -> float32 [n,5] = x,y,z,distance,weight (submap frame)."""
+    idx, vox = layer.download()
+    d, w, _ = words_to_fields(vox)
+    vs = np.float32(layer.voxel_size)
+    lin = np.arange(4096)
+    loc = np.stack([lin % 16, (lin // 16) % 16, lin // 256], axis=1)
+    out = []
+    for b in range(len(idx)):
+        m = (w[b] > min_weight) & (np.abs(d[b]) < trunc)
+        g = idx[b][None, :] * 16 + loc[m]
+        c = ((g.astype(np.float32) + 0.5) * vs).astype(np.float32)
+        out.append(np.concatenate([c, d[b][m, None], w[b][m, None]], axis=1))
+    return np.concatenate(out, axis=0).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def submaps(hip, oracle):
+    """Two overlapping submaps of one client (frames 0-11 and 6-17, every 6th pixel), built by the ORACLE and
+    uploaded to both engines so the registration inputs are identical on both sides."""
+    la, _, _ = run_frames(oracle, method="merged", voxel=0.10, frames=range(0, 60, 5), subsample=6)
+    lb, _, _ = run_frames(oracle, method="merged", voxel=0.10, frames=range(30, 90, 5), subsample=6)
+    pts = registration_points(la, 0.3)
+    idx, vox = lb.download()
+    lh = Layer(hip, 0.10, capacity_blocks=4096)
+    lh.upload(idx, vox)
+    return pts, lb, lh
+
+
+def _pair(hip, oracle, submaps, ncc=0.0):
+    pts, lb, lh = submaps
+    return Registration(hip, RegPoints(hip, pts), lh, ncc), Registration(oracle, RegPoints(oracle, pts), lb, ncc), pts
+
+
+@pytest.mark.parametrize("pose", [((0, 0, 0, 0), (0, 0, 0, 0)), ((0.02, -0.01, 0.0, 0.01), (0.05, -0.03, 0.02, np.radians(1.0))),
+                                  ((1.0, 2.0, -0.5, 0.7), (1.04, 1.97, -0.52, 0.68))])
+def test_evaluate_matches_oracle(hip, oracle, submaps, pose):
+    gh, go, pts = _pair(hip, oracle, submaps)
+    pr, pd = np.array(pose[0], float), np.array(pose[1], float)
+    rh, jfh, jrh = gh.evaluate(pr, pd)
+    ro, jfo, jro = go.evaluate(pr, pd)
+    assert len(ro) == len(pts) > 5000
+    assert np.count_nonzero(ro) > 0.3 * len(ro)
+    assert np.max(np.abs(rh - ro)) <= 1e-4
+    for a, b in ((jfh, jfo), (jrh, jro)):
+        assert np.max(np.abs(a - b)) <= 1e-3 * max(1.0, float(np.max(np.abs(b))))
+    print("max |dr|", np.max(np.abs(rh - ro)), "bit-exact residuals:", np.array_equal(rh, ro), "J:", np.array_equal(jfh, jfo), np.array_equal(jrh, jro))
+
+
+def test_sampled_evaluate_and_normal_equations(hip, oracle, submaps):
+    gh, go, pts = _pair(hip, oracle, submaps, ncc=0.05)
+    rng = np.random.default_rng(7)
+    w = pts[:, 4].astype(np.float64)
+    n_res = int(0.3 * len(pts))  # sampling_ratio 0.3 (coxgraph/config/server.yaml:30), weight-proportional, with replacement
+    idx = rng.choice(len(pts), size=n_res, replace=True, p=w / w.sum()).astype(np.uint32)
+    pr, pd = np.array([0.0, 0, 0, 0]), np.array([0.05, -0.03, 0.02, np.radians(1.0)])
+    rh, jfh, jrh = gh.evaluate(pr, pd, idx)
+    ro, jfo, jro = go.evaluate(pr, pd, idx)
+    assert np.max(np.abs(rh - ro)) <= 1e-4
+    Hh, bh, ch, nh = gh.normal_eq(pr, pd, idx)
+    Ho, bo, co, no = go.normal_eq(pr, pd, idx)
+    assert nh == no and 0 < nh <= n_res
+    scale = max(1.0, float(np.max(np.abs(Ho))))
+    assert np.max(np.abs(Hh - Ho)) <= 1e-6 * scale
+    assert np.max(np.abs(bh - bo)) <= 1e-6 * max(1.0, float(np.max(np.abs(bo))))
+    assert abs(ch - co) <= 1e-6 * max(1.0, co)
+    # the fused reduction equals J^T J of the materialised Jacobian
+    J = np.concatenate([jfh, jrh], axis=1)
+    assert np.allclose(Hh, J.T @ J, rtol=1e-9, atol=1e-9 * scale)
+    assert np.allclose(bh, J.T @ rh, rtol=1e-9, atol=1e-9 * scale)
+    assert np.allclose(Hh, Hh.T)
+    # reproducible run to run (fixed reduction order)
+    H2, b2, c2, _ = gh.normal_eq(pr, pd, idx)
+    assert np.array_equal(Hh, H2) and np.array_equal(bh, b2) and ch == c2
+
+
+def test_jacobian_against_central_differences_on_gpu(hip, oracle, submaps):
+    gh, _, pts = _pair(hip, oracle, submaps)
+    pr, pd = np.array([0.01, 0.02, -0.01, 0.01]), np.array([0.03, -0.02, 0.01, -0.01])
+    r0, jf, jr = gh.evaluate(pr, pd)
+    h = 2e-3
+    ok = r0 != 0
+    for k in range(4):
+        e = np.zeros(4)
+        e[k] = h
+        rp = gh.evaluate(pr + e, pd, jacobians=False)[0]
+        rm = gh.evaluate(pr - e, pd, jacobians=False)[0]
+        m = ok & (rp != 0) & (rm != 0)
+        num = (rp - rm) / (2 * h)
+        # trilinear field is only piecewise smooth: compare in the median, not pointwise
+        err = np.abs(num[m] - jf[m, k])
+        assert np.median(err) < 0.05 * max(1e-3, float(np.median(np.abs(jf[m, k])))) + 1e-3, (k, np.median(err))
+
+
+def test_edge_cases(hip, oracle, submaps):
+    pts, lb, lh = submaps
+    # empty point set
+    g0 = Registration(hip, RegPoints(hip, np.zeros((0, 5), np.float32)), lh)
+    H, b, c, n = g0.normal_eq(np.zeros(4), np.zeros(4))
+    assert not H.any() and not b.any() and c == 0 and n == 0
+    # reference far away from the reading submap: no correspondences at all -> residual = w * no_correspondence_cost * scale
+    far = pts[:300].copy()
+    far[:, :3] += 500.0
+    gh = Registration(hip, RegPoints(hip, far), lh, 0.25)
+    go = Registration(oracle, RegPoints(oracle, far), lb, 0.25)
+    rh, jfh, _ = gh.evaluate(np.zeros(4), np.zeros(4))
+    ro, _, _ = go.evaluate(np.zeros(4), np.zeros(4))
+    assert np.array_equal(rh, ro) or np.max(np.abs(rh - ro)) < 1e-12
+    assert not jfh.any()
+    assert gh.normal_eq(np.zeros(4), np.zeros(4))[3] == 0
