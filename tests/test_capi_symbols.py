@@ -40,7 +40,7 @@ def test_no_gpu_calls_fail_cleanly(hip):
     f = hip.fn("status_string", C.c_char_p)
     assert f(-4) == b"COX_ERR_POOL_EXHAUSTED"
     cfg = hip.default_config()
-    assert abs(cfg.default_truncation_distance - 0.1) < 1e-9 and cfg.max_weight == 10000.0
+    assert abs(cfg.default_truncation_distance - 0.1) < 1e-7 and cfg.max_weight == 10000.0
 
 
 def test_product_package_has_no_oracle_or_cpu_fallback():
