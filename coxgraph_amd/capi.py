@@ -1,9 +1,9 @@
 """ctypes binding of the C ABI declared in include/coxgraph_hip.h.
 
 The binding is generic over (shared library, symbol prefix): the product engine is
-``coxgraph_amd/lib/libcoxgraph_hip.so`` with prefix ``cox_``; the test suite loads the CPU oracle
-(``oracle/libcoxoracle.so``, prefix ``coxo_``) through the same classes so parity tests read the
-same on both sides.  Nothing in this package loads the oracle.
+``coxgraph_amd/lib/libcoxgraph_hip.so`` with prefix ``cox_``; the test suite loads its CPU checker
+(built from ``oracle/``, its own symbol prefix) through the same classes so parity tests read the
+same on both sides.  Nothing in this package loads that checker.
 """
 import ctypes as C
 import os
