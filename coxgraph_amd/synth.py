@@ -1,7 +1,8 @@
 """Deterministic synthetic depth stream for the benchmark and parity tests.
 
 Scene: axis-aligned room, interior [-4,4] x [-3,3] x [0,3] m (world frame G, z up) plus a sphere
-r = 0.75 m at (1.5, 0.5, 1.0).  Depth by analytic ray/plane + ray/sphere intersection in float64,
+r = 0.75 m at (2.5, 0.5, 1.0) (SURVEY.md proposed x = 1.5, which puts the surface 0.12 m from the camera
+circle and makes a third of the frame invalid by min_ray_length; moved 1 m outward).  Depth by analytic ray/plane + ray/sphere intersection in float64,
 rounded to float32.  Camera: pinhole, z-forward optical frame; the 640x480 intrinsics are the
 RealSense ones the reference ships (coxgraph/config/realsense/rs_config_0.yaml:12-24).
 Trajectory of client k of K: circle radius 1 m, height 1.5 m, yaw(t) = 2*pi*k/K + 0.36 deg * t looking
@@ -17,7 +18,7 @@ INTRINSICS = {
 }
 ROOM_MIN = np.array([-4.0, -3.0, 0.0])
 ROOM_MAX = np.array([4.0, 3.0, 3.0])
-SPHERE_C = np.array([1.5, 0.5, 1.0])
+SPHERE_C = np.array([2.5, 0.5, 1.0])
 SPHERE_R = 0.75
 
 # integrator parameters per voxel size, from the reference's yaml files

@@ -58,7 +58,10 @@ def test_synthetic_scene_is_deterministic_and_plausible():
     T2, pts2, _, _ = synth.make_frame(0)
     assert np.array_equal(pts, pts2) and np.array_equal(T, T2)
     assert pts.shape == (640 * 480, 3) and rgba.shape == (640 * 480, 4)
-    assert 0.5 < depth.min() < depth.max() < 6.0
+    assert 0.5 < depth.min() < depth.max() < 6.0  # nothing closer than min_ray_length
     assert abs(np.linalg.norm(T[:4]) - 1.0) < 1e-6
-    # camera looks outward along +x at t = 0: the wall at x = 4 is 3 m ahead of the camera at x = 1
-    assert abs(depth[245, 323] - 3.0) < 1e-3
+    # camera at (1, 0, 1.5) looks outward along +x at t = 0; the sphere (centre (2.5, 0.5, 1.0), r 0.75) is hit
+    # by the central ray: analytic first intersection of x -> 1 + s along +x is s = 1.5 - sqrt(0.75^2 - 0.5) = 1.25
+    assert abs(depth[245, 323] - 1.25) < 5e-3
+    # the corners see the front wall x = 4, 3 m ahead (z-depth, not range)
+    assert abs(depth[0, 0] - 3.0) < 1e-5
