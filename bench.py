@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 640x480 depth frames/s fused into a 5 cm TSDF submap per MI355X
+(BASELINE.json configs[1]) + submap registrations/s, one coxgraph client per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic depth frame: integratePointCloud(T_G_C,
+points_C, colors) of 307 200 points into the client's submap layer, inputs already resident in HBM.
+For N > 1 the driver launches one rank per GPU (torch.distributed over RCCL); clients are independent
+(weak scaling, no data-path collective -- SURVEY.md section 8e); the only collective is the
+barrier/max-reduce of the timing harness.
+
+One JSON line on rank 0.  `roofline` prices the dominant kernel against HBM peak using the ALGORITHMIC
+bytes of SURVEY.md section 8d (16 B per valid point + 24 B per touched voxel); `cpu_baseline` times
+the CPU restatement of the reference's configured integrator (fast, 8 threads) on a bounded sample of
+the same frames on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--method", default="merged", choices=["merged", "simple"])
+    ap.add_argument("--voxel", type=float, default=0.05)
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--reg-iters", type=int, default=50)
+    ap.add_argument("--no-profile-pass", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, voxel, n_frames, threads):
+    """Oracle 'fast' integrator (the reference's configured method, tsdf_server_euroc.yaml:6,10) on host cores."""
+    from coxgraph_amd import synth
+    from coxgraph_amd.capi import Engine, Layer, Integrator
+    import ctypes as C
+    lib = os.path.join(ROOT, "oracle", "libcoxoracle.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build_oracle()
+    eng = Engine(lib, "coxo_")
+    out = {}
+    for method, thr in (("fast", threads), ("merged", 1)):
+        cfg = eng.default_config(integrator_threads=thr, **synth.integrator_overrides(voxel))
+        layer = Layer(eng, voxel)
+        integ = Integrator(eng, layer, cfg, method)
+        eng.fn("integrator_set_count_touched")(integ.h, C.c_int(0))
+        nf = n_frames if method == "fast" else max(2, n_frames // 4)
+        t0 = time.perf_counter()
+        for (T, pts, rgba) in frames[:nf]:
+            integ.integrate_points(T, pts, rgba)
+        dt = time.perf_counter() - t0
+        out[method] = (nf / dt, nf, dt)
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import coxgraph_amd
+    from coxgraph_amd import synth
+    from coxgraph_amd.capi import Layer, Integrator, RegPoints, Registration, words_to_fields
+    eng = coxgraph_amd.load_engine()
+
+    # ---- synthetic stream of this rank's client, resident in HBM before anything is timed ----------
+    n_frames = args.warmup + args.steps
+    host_frames = []
+    dev_frames = []
+    for t in range(n_frames):
+        T, pts, rgba, _ = synth.make_frame(t, client=rank, n_clients=max(world, 1))
+        if t < max(args.cpu_frames, 1):
+            host_frames.append((T, pts, rgba))
+        dev_frames.append((T, torch.from_numpy(pts).cuda(), torch.from_numpy(rgba).cuda(), pts.shape[0]))
+    torch.cuda.synchronize()
+
+    cfg = eng.default_config(**synth.integrator_overrides(args.voxel))
+    layer = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+    integ = Integrator(eng, layer, cfg, args.method)
+
+    def step(i):
+        T, xyz, rgba, n = dev_frames[i]
+        integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+
+    for i in range(args.warmup):
+        step(i)
+    integ.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_frames):
+        step(i)
+    integ.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fps = world * args.steps / dt
+
+    # ---- roofline of the dominant kernel: same frames again on a fresh layer with HIP-event timing ------
+    roofline = None
+    stats_sum = dict(n_valid=0, n_touched_voxels=0, n_updates=0, n_rays=0)
+    if rank == 0 and not args.no_profile_pass:
+        layer2 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+        integ2 = Integrator(eng, layer2, cfg, args.method)
+        integ2.set_profiling(True)
+        for i in range(n_frames):
+            T, xyz, rgba, n = dev_frames[i]
+            integ2.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+            if i >= args.warmup:
+                st = integ2.last_stats()
+                for k in stats_sum:
+                    stats_sum[k] += st[k]
+            elif i == args.warmup - 1:
+                integ2.kernel_time(reset=True)
+        ms, launches = integ2.kernel_time()
+        alg_bytes = 16.0 * stats_sum["n_valid"] + 24.0 * stats_sum["n_touched_voxels"]
+        if launches:
+            per_launch_bytes = alg_bytes / launches
+            avg_ms = ms / launches
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_apply_short+k_apply_long (TSDF update stage)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms,
+                        "algorithmic_bytes_per_launch": per_launch_bytes,
+                        "updates_per_s_in_kernel": stats_sum["n_updates"] / (ms * 1e-3)}
+        del integ2, layer2
+
+    # ---- registrations/s: one fused residual+Jacobian+normal-equation evaluation of one constraint ------
+    reg = None
+    if rank == 0 and args.reg_iters > 0:
+        idx, vox = layer.download()
+        d, w, _ = words_to_fields(vox)
+        trunc = cfg.default_truncation_distance
+        lin = np.arange(4096)
+        loc = np.stack([lin % 16, (lin // 16) % 16, lin // 256], axis=1)
+        pts = []
+        for b in range(len(idx)):
+            m = (w[b] > 1.0) & (np.abs(d[b]) < trunc)
+            c = ((idx[b][None, :] * 16 + loc[m]).astype(np.float32) + 0.5) * np.float32(args.voxel)
+            pts.append(np.concatenate([c, d[b][m, None], w[b][m, None]], axis=1))
+        pts = np.concatenate(pts, axis=0).astype(np.float32)
+        rng = np.random.default_rng(7)
+        ww = pts[:, 4].astype(np.float64)
+        n_res = int(0.3 * len(pts))  # sampling_ratio 0.3, coxgraph/config/server.yaml:30
+        sidx = rng.choice(len(pts), size=n_res, replace=True, p=ww / ww.sum()).astype(np.uint32)
+        g = Registration(eng, RegPoints(eng, pts, device=local_rank), layer)
+        pr, pd = np.zeros(4), np.array([0.05, -0.03, 0.02, np.radians(1.0)])
+        g.normal_eq(pr, pd, sidx)
+        g.kernel_time(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(args.reg_iters):
+            g.normal_eq(pr, pd, sidx)
+        dtr = time.perf_counter() - t1
+        kms, kl = g.kernel_time()
+        reg = {"registrations_per_s": args.reg_iters / dtr, "residuals_per_registration": n_res, "registration_points": int(len(pts)),
+               "kernel_ms": kms / max(kl, 1), "kernel_GBps_algorithmic": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9}
+
+    # ---- CPU baseline on rank 0, N = 1 only ---------------------------------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        threads = min(8, os.cpu_count() or 1)
+        res = cpu_baseline(host_frames, args.voxel, min(args.cpu_frames, len(host_frames)), threads)
+        cpu = {"value": res["fast"][0], "unit": "frames/s", "cores": threads, "kind": "port",
+               "sample": f"oracle FastTsdfIntegrator restatement, {threads} threads (reference integrator_threads: 8), first {res['fast'][1]} frames of the "
+                         f"same stream, {res['fast'][2]:.1f} s; oracle merged 1 thread: {res['merged'][0]:.2f} frames/s over {res['merged'][1]} frames",
+               "merged_1thread_frames_per_s": res["merged"][0]}
+
+    if rank == 0:
+        line = {
+            "metric": "640x480 depth frames/sec fused (TSDF, 5 cm voxels) per node; submap registrations/sec reported alongside",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: 1 client per GPU, 640x480 synthetic depth stream, {args.voxel * 100:.0f} cm voxels, "
+                                   f"{args.method} integrator semantics (bit-exact vs CPU oracle), points resident in HBM",
+                       "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
+            "frame_stats_mean": {k: v / max(args.steps, 1) for k, v in stats_sum.items()},
+            "roofline": roofline, "cpu_baseline": cpu, "registration": reg,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,10 +92,21 @@ __device__ __forceinline__ u32 hash_key(u64 k) {
 __device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // ---- open-addressing hash set/map on packed keys -------------------------------------------
-// insert-or-find; returns the slot, *fresh = true when this thread claimed it
+// insert-or-find; returns the slot, *fresh = true when this thread claimed it.
+// The slot is first read with an agent-scope load (served past the non-coherent L1): thousands of
+// rays ask for the same few dozen blocks per frame and same-address CAS round trips serialise.
 __device__ __forceinline__ u32 ht_insert(u64* keys, u32 mask, u64 key, bool* fresh) {
   u32 slot = hash_key(key) & mask;
   for (u32 probe = 0; probe <= mask; ++probe) {
+    const u64 seen = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == key) {
+      *fresh = false;
+      return slot;
+    }
+    if (seen != kEmptyKey) {
+      slot = (slot + 1) & mask;
+      continue;
+    }
     const u64 prev = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), static_cast<unsigned long long>(kEmptyKey),
                                static_cast<unsigned long long>(key));
     if (prev == kEmptyKey) {

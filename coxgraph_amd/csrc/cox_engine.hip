@@ -108,6 +108,7 @@ const char* cox_status_string(int s) {
 }
 
 int cox_device_count(void) {
+  COX_ENTRY();
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
@@ -137,6 +138,7 @@ void cox_tsdf_config_default(cox_tsdf_config* c) {
 }
 
 int cox_layer_create(float voxel_size, int voxels_per_side, int device, uint64_t capacity_blocks, cox_layer_t** out) {
+  COX_ENTRY();
   if (!out || !(voxel_size > 0.0f) || voxels_per_side != kVps) return COX_ERR_INVALID_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return COX_ERR_NO_DEVICE;
@@ -196,6 +198,7 @@ void cox_layer_destroy(cox_layer_t* L) {
 }
 
 int cox_layer_clear(cox_layer_t* L) {
+  COX_ENTRY();
   if (!L) return COX_ERR_INVALID_ARG;
   u32 nb, err;
   int st = layer_read_counters(L, &nb, &err);
@@ -207,6 +210,7 @@ int cox_layer_clear(cox_layer_t* L) {
 }
 
 int cox_layer_stats(cox_layer_t* L, uint64_t* n_blocks, uint64_t* memory_bytes) {
+  COX_ENTRY();
   if (!L) return COX_ERR_INVALID_ARG;
   u32 nb, err;
   int st = layer_read_counters(L, &nb, &err);
@@ -217,6 +221,7 @@ int cox_layer_stats(cox_layer_t* L, uint64_t* n_blocks, uint64_t* memory_bytes) 
 }
 
 int cox_layer_download(cox_layer_t* L, int32_t* block_idx_xyz, uint32_t* voxels_3u32, uint64_t cap_blocks, uint64_t* n_blocks) {
+  COX_ENTRY();
   if (!L) return COX_ERR_INVALID_ARG;
   u32 nb, err;
   int st = layer_read_counters(L, &nb, &err);
@@ -305,6 +310,7 @@ __global__ void __launch_bounds__(256) k_upload_copy(u32* __restrict__ voxels, c
 }
 
 extern "C" int cox_layer_upload(cox_layer_t* L, const int32_t* block_idx_xyz, const uint32_t* voxels_3u32, uint64_t n_blocks, int action) {
+  COX_ENTRY();
   if (!L || action < 0 || action > 2 || (n_blocks && (!block_idx_xyz || !voxels_3u32))) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(L->device));
   if (action == 2) {
@@ -482,54 +488,80 @@ __global__ void __launch_bounds__(256) k_bundle_starts(u32 n, const u32* __restr
   const u32 k = skey[i];
   if (k != kInvalid && (i == 0 || skey[i - 1] != k)) bstart[head_scan[i]] = i;
 }
-// thread = bundle: sequential weighted mean of its points in visiting order (bit-exact with the
-// single-threaded reference loop), then the ray set-up.  Threads beyond the bundle count clear nsteps.
+// wave = bundle: the sequential weighted mean of its points in visiting order (bit-exact with the
+// single-threaded reference loop).  64 points at a time are gathered in parallel; the running mean
+// itself is a dependent chain and is evaluated uniformly by the whole wave out of registers.
+__device__ __forceinline__ float readlane_f32(float v, u32 lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+
 __global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba,
                                                       const u32* __restrict__ skey, const u32* __restrict__ sval, const u32* __restrict__ bstart,
                                                       RayArrays R, Counters* cnt) {
-  const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= P.n_points) return;
   const u32 n_bundles = cnt->n_rays;  // written by the scan of head flags
-  if (m >= n_bundles) {
+  const u32 n_valid = cnt->n_valid;
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nthreads = gridDim.x * blockDim.x;
+  // ray slots beyond the bundle count emit nothing
+  for (u32 m = n_bundles + tid; m < P.n_points; m += nthreads) {
     R.nsteps[m] = 0;
     R.flags[m] = 0;
-    return;
   }
-  const u32 begin = bstart[m];
-  const u32 end = (m + 1 < n_bundles) ? bstart[m + 1] : cnt->n_valid;
-  const bool clearing = skey[begin] >= np2;
-  float mx = 0.0f, my = 0.0f, mz = 0.0f, W = 0.0f;
-  u32 mcolor = 0;
-  u64 key = 0;
-  for (u32 i = begin; i < end; ++i) {
-    const u32 idx = mixed_index(sval[i], P.n_points);
-    const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
-    if (i == begin) {
-      const F3 pg = transform_point(P, p);
-      key = pack_key(grid_index(pg.x * P.voxel_size_inv), grid_index(pg.y * P.voxel_size_inv), grid_index(pg.z * P.voxel_size_inv));
+  const u32 lane = lane_id();
+  for (u32 m = tid >> 6; m < n_bundles; m += nthreads >> 6) {
+    const u32 begin = bstart[m];
+    const u32 end = (m + 1 < n_bundles) ? bstart[m + 1] : n_valid;
+    const bool clearing = skey[begin] >= np2;
+    float mx = 0.0f, my = 0.0f, mz = 0.0f, W = 0.0f;
+    u32 mcolor = 0;
+    u64 key = 0;
+    bool done = false;
+    for (u32 base = begin; base < end && !done; base += 64) {
+      const u32 i = base + lane;
+      float px = 0.0f, py = 0.0f, pz = 0.0f, w = 0.0f;
+      u32 col = 0;
+      if (i < end) {
+        const u32 idx = mixed_index(sval[i], P.n_points);
+        px = xyz[3 * idx];
+        py = xyz[3 * idx + 1];
+        pz = xyz[3 * idx + 2];
+        w = voxel_weight(P, F3{px, py, pz});
+        col = pack_rgba_wire(rgba, idx);
+      }
+      if (base == begin) {
+        const F3 pg = transform_point(P, F3{readlane_f32(px, 0), readlane_f32(py, 0), readlane_f32(pz, 0)});
+        key = pack_key(grid_index(pg.x * P.voxel_size_inv), grid_index(pg.y * P.voxel_size_inv), grid_index(pg.z * P.voxel_size_inv));
+      }
+      const u32 cnt_in = min(64u, end - base);
+      for (u32 k = 0; k < cnt_in; ++k) {
+        const float w1 = readlane_f32(w, k);
+        if (w1 < kEps) continue;
+        const float x1 = readlane_f32(px, k), y1 = readlane_f32(py, k), z1 = readlane_f32(pz, k);
+        const float den = W + w1;
+        mx = (mx * W + x1 * w1) / den;
+        my = (my * W + y1 * w1) / den;
+        mz = (mz * W + z1 * w1) / den;
+        mcolor = blend_colors(mcolor, W, static_cast<u32>(__builtin_amdgcn_readlane(col, k)), w1);
+        W += w1;
+        if (clearing) {  // only the first point of a clearing bundle is used
+          done = true;
+          break;
+        }
+      }
     }
-    const float w = voxel_weight(P, p);
-    if (w < kEps) continue;
-    const float den = W + w;
-    mx = (mx * W + p.x * w) / den;
-    my = (my * W + p.y * w) / den;
-    mz = (mz * W + p.z * w) / den;
-    mcolor = blend_colors(mcolor, W, pack_rgba_wire(rgba, idx), w);
-    W += w;
-    if (clearing) break;  // only the first point of a clearing bundle is used
+    if (lane == 0) {
+      const F3 pg = transform_point(P, F3{mx, my, mz});
+      Dda d;
+      dda_setup(d, P, pg, clearing);
+      if (d.range_error) atomicOr(&cnt->err, kErrRange);
+      R.px[m] = pg.x;
+      R.py[m] = pg.y;
+      R.pz[m] = pg.z;
+      R.w[m] = W;
+      R.color[m] = mcolor;
+      R.flags[m] = 1u | (clearing ? 2u : 0u);
+      R.key[m] = key;
+      R.nsteps[m] = d.nsteps;
+    }
   }
-  const F3 pg = transform_point(P, F3{mx, my, mz});
-  Dda d;
-  dda_setup(d, P, pg, clearing);
-  if (d.range_error) atomicOr(&cnt->err, kErrRange);
-  R.px[m] = pg.x;
-  R.py[m] = pg.y;
-  R.pz[m] = pg.z;
-  R.w[m] = W;
-  R.color[m] = mcolor;
-  R.flags[m] = 1u | (clearing ? 2u : 0u);
-  R.key[m] = key;
-  R.nsteps[m] = d.nsteps;
 }
 
 // ---- touch: allocate blocks, give every block touched this frame a dense ordinal ---------------
@@ -577,7 +609,8 @@ __global__ void __launch_bounds__(256) k_touch(FrameParams P, RayArrays R, u32 n
         atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped
       }
     }
-    if (atomicExch(&L.ht_stamp[slot], P.frame_id) != P.frame_id) {
+    if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
+        atomicExch(&L.ht_stamp[slot], P.frame_id) != P.frame_id) {
       const u32 ord = atomicAdd(&cnt->n_touched, 1u);
       touched_slots[ord] = slot;
       L.ht_ord[slot] = ord;
@@ -623,60 +656,17 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams P, RayArrays R, u32 n_
   }
 }
 
-// ---- segments: one per voxel touched ------------------------------------------------------------
-// A segment whose end is visible inside the wave that holds its head is "short" (<= 64 records) and is
-// applied by one thread; the others are "long" and get a whole wave.
-__global__ void __launch_bounds__(256) k_segments(const u32* __restrict__ rec_key, const u32* __restrict__ d_n, u32* __restrict__ short_start,
-                                                  u32* __restrict__ short_len, u32* __restrict__ long_start, Counters* cnt) {
-  const u32 n = *d_n;
-  const u32 lane = lane_id();
-  const u32 wave_base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
-  if (wave_base >= n) return;
-  const u32 i = wave_base + lane;
-  const bool in = i < n;
-  const u32 key = in ? rec_key[i] : kInvalid;
-  const u32 prev = (in && i > 0) ? rec_key[i - 1] : ~key;
-  const bool boundary = !in || (key != prev) || i == 0;
-  const bool head = in && boundary && key != kInvalid;
-  const u64 bmask = __ballot(boundary);
-  const u64 valid_mask = __ballot(in && key != kInvalid);
-  // next boundary strictly after this lane, inside the wave
-  const u64 later = (lane == 63) ? 0ull : (bmask >> (lane + 1));
-  bool is_short = false, is_long = false;
-  u32 len = 0;
-  if (head) {
-    if (later) {
-      len = static_cast<u32>(__ffsll(static_cast<long long>(later)));
-      is_short = true;
-    } else {
-      const u32 nxt = wave_base + 64;
-      if (nxt >= n || rec_key[nxt] != key) {
-        len = min(nxt, n) - i;
-        is_short = true;
-      } else {
-        is_long = true;
-      }
-    }
-  }
-  const u64 smask = __ballot(is_short), lmask = __ballot(is_long);
-  u32 sbase = 0, lbase = 0;
-  if (lane == 0) {
-    if (smask) sbase = atomicAdd(&cnt->n_short, static_cast<u32>(__popcll(smask)));
-    if (lmask) lbase = atomicAdd(&cnt->n_long, static_cast<u32>(__popcll(lmask)));
-    if (valid_mask) atomicAdd(&cnt->n_updates, static_cast<u32>(__popcll(valid_mask)));
-  }
-  sbase = __shfl(sbase, 0, 64);
-  lbase = __shfl(lbase, 0, 64);
-  const u64 lt = (1ull << lane) - 1ull;
-  if (is_short) {
-    const u32 pos = sbase + static_cast<u32>(__popcll(smask & lt));
-    short_start[pos] = i;
-    short_len[pos] = len;
-  }
-  if (is_long) long_start[lbase + static_cast<u32>(__popcll(lmask & lt))] = i;
-}
-
-// ---- apply ----------------------------------------------------------------------------------------
+// ---- apply: per voxel, the running weighted-mean / clamp update in canonical ray order -----------------
+// After the stable sort the records of one voxel are contiguous ("segment") and in ray order.
+// One wave owns 64 consecutive records:
+//   1. every lane evaluates its own record (voxel centre, sdf, update weight, colour) -- the costly,
+//      order-independent part -- fully in parallel;
+//   2. the head lane of every segment that ends inside the wave replays its records in order out of the
+//      neighbours' registers (__shfl), at most 63 dependent steps;
+//   3. a segment that runs past the wave ("long": at most one per wave, a few near-camera voxels that
+//      every ray crosses) is then folded by the whole wave, 64 records per step; runs of free-space
+//      observations over a voxel already sitting at +trunc are collapsed exactly (saturating_update).
+// No atomics on the data path; results are bit-reproducible run to run.
 struct VoxelRef {
   u32* ptr;  // 3 words
   int gx, gy, gz;
@@ -697,89 +687,141 @@ __device__ __forceinline__ VoxelRef locate_voxel(const LayerView& L, const u32* 
   return v;
 }
 
-__global__ void __launch_bounds__(256) k_apply_short(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots,
-                                                     const u32* __restrict__ rec_key, const u32* __restrict__ rec_ray, const u32* __restrict__ short_start,
-                                                     const u32* __restrict__ short_len, const Counters* cnt) {
-  const u32 n = cnt->n_short;
-  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const u32 start = short_start[j], len = short_len[j];
-    const VoxelRef vr = locate_voxel(L, touched_slots, rec_key[start]);
-    if (!vr.ok) continue;
-    Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
-    for (u32 k = 0; k < len; ++k) {
-      const u32 r = rec_ray[start + k];
-      const F3 pg{R.px[r], R.py[r], R.pz[r]};
-      const float sdf = compute_sdf(P, pg, vr.gx, vr.gy, vr.gz);
-      const float uw = update_weight(P, sdf, R.w[r]);
-      update_voxel(P, v, sdf, uw, R.color[r]);
-    }
-    vr.ptr[0] = __float_as_uint(v.d);
-    vr.ptr[1] = __float_as_uint(v.w);
-    vr.ptr[2] = v.c;
+__global__ void __launch_bounds__(256) k_apply(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots,
+                                               const u32* __restrict__ rec_key, const u32* __restrict__ rec_ray, const u32* __restrict__ d_nrec,
+                                               Counters* cnt) {
+  __shared__ u32 blk_updates, blk_voxels;
+  if (threadIdx.x == 0) {
+    blk_updates = 0;
+    blk_voxels = 0;
   }
-}
-
-__device__ __forceinline__ float readlane_f(float v, u32 lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
-
-// one wave per long segment; 64 records per step are evaluated in parallel (sdf, weight), the
-// running update itself is applied in order.  Runs of free-space observations over a voxel that
-// already sits at +trunc are folded exactly (saturating_update).
-__global__ void __launch_bounds__(256) k_apply_long(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots,
-                                                    const u32* __restrict__ rec_key, const u32* __restrict__ rec_ray, const u32* __restrict__ d_nrec,
-                                                    const u32* __restrict__ long_start, const Counters* cnt) {
-  const u32 n_long = cnt->n_long;
-  const u32 n_rec = *d_nrec;
+  __syncthreads();
+  const u32 n = *d_nrec;
   const u32 lane = lane_id();
-  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  for (u32 j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; j < n_long; j += waves_total) {
-    const u32 start = long_start[j];
-    const u32 key = rec_key[start];
-    const VoxelRef vr = locate_voxel(L, touched_slots, key);
-    if (!vr.ok) continue;
-    Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
-    for (u32 base = start;; base += 64) {
-      const u32 i = base + lane;
-      const bool in = (i < n_rec) && (rec_key[i] == key);
-      float sdf = 0.0f, uw = 0.0f;
-      u32 color = 0;
-      bool sat = false;
-      if (in) {
-        const u32 r = rec_ray[i];
-        const F3 pg{R.px[r], R.py[r], R.pz[r]};
-        sdf = compute_sdf(P, pg, vr.gx, vr.gy, vr.gz);
-        uw = update_weight(P, sdf, R.w[r]);
-        color = R.color[r];
-        sat = saturating_update(P, sdf, uw);
-      }
-      const u64 in_mask = __ballot(in);
-      const u32 cnt_in = static_cast<u32>(__popcll(in_mask));  // the segment is contiguous: lanes [0, cnt_in)
-      if (cnt_in == 0) break;
-      const bool all_sat = __ballot(in && sat) == in_mask;
-      if (all_sat && v.d == P.trunc) {
-        // distance provably stays at +trunc; only the weight moves
-        const bool unit = __ballot(in && uw == 1.0f) == in_mask;
-        if (v.w >= P.max_weight) {
-          // min(max_weight, w + u) == max_weight for every u > 0
-        } else if (unit && v.w == truncf(v.w) && v.w + static_cast<float>(cnt_in) < 16777216.0f) {
-          v.w = std_min(P.max_weight, v.w + static_cast<float>(cnt_in));  // integers add exactly
-        } else {
-          for (u32 k = 0; k < cnt_in; ++k) {
-            const float nw = v.w + readlane_f(uw, k);
-            if (!(nw < kEps)) v.w = std_min(P.max_weight, nw);
-          }
-        }
-      } else {
-        for (u32 k = 0; k < cnt_in; ++k) {
-          update_voxel(P, v, readlane_f(sdf, k), readlane_f(uw, k), static_cast<u32>(__builtin_amdgcn_readlane(color, k)));
-        }
-      }
-      if (cnt_in < 64) break;
+  const u32 wave_base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
+  if (wave_base < n) {
+    const u32 i = wave_base + lane;
+    const bool in = i < n;
+    const u32 key = in ? rec_key[i] : kInvalid;
+    const u32 prev = (in && i > 0) ? rec_key[i - 1] : ~key;
+    const bool valid = in && key != kInvalid;
+    const bool boundary = !in || (key != prev) || i == 0;
+    const bool head = valid && boundary;
+    // ---- 1. per-record evaluation --------------------------------------------------------------------
+    VoxelRef vr{nullptr, 0, 0, 0, false};
+    float sdf = 0.0f, uw = 0.0f;
+    u32 color = 0;
+    if (valid) {
+      vr = locate_voxel(L, touched_slots, key);
+      const u32 r = rec_ray[i];
+      const F3 pg{R.px[r], R.py[r], R.pz[r]};
+      sdf = compute_sdf(P, pg, vr.gx, vr.gy, vr.gz);
+      uw = update_weight(P, sdf, R.w[r]);
+      color = R.color[r];
     }
-    if (lane == 0) {
+    // ---- segment geometry -----------------------------------------------------------------------------
+    const u64 bmask = __ballot(boundary);
+    const u64 later = (lane == 63) ? 0ull : (bmask >> (lane + 1));
+    u32 len = 0;
+    bool is_long = false;
+    if (head) {
+      if (later) {
+        len = static_cast<u32>(__ffsll(static_cast<long long>(later)));
+      } else {
+        const u32 nxt = wave_base + 64;
+        if (nxt >= n || rec_key[nxt] != key)
+          len = min(nxt, n) - i;
+        else
+          is_long = true;
+      }
+    }
+    // ---- 2. short segments: head lanes replay their records in order ----------------------------------
+    const bool run_short = head && !is_long && vr.ok;
+    Voxel v{0.0f, 0.0f, 0u};
+    if (run_short) {
+      v.d = __uint_as_float(vr.ptr[0]);
+      v.w = __uint_as_float(vr.ptr[1]);
+      v.c = vr.ptr[2];
+    }
+    u32 max_len = run_short ? len : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(static_cast<int>(max_len), off, 64)));
+    for (u32 k = 0; k < max_len; ++k) {
+      const int src = static_cast<int>((lane + k) & 63u);
+      const float s_k = __shfl(sdf, src, 64);
+      const float u_k = __shfl(uw, src, 64);
+      const u32 c_k = static_cast<u32>(__shfl(static_cast<int>(color), src, 64));
+      if (run_short && k < len) update_voxel(P, v, s_k, u_k, c_k);
+    }
+    if (run_short) {
       vr.ptr[0] = __float_as_uint(v.d);
       vr.ptr[1] = __float_as_uint(v.w);
       vr.ptr[2] = v.c;
     }
+    // ---- 3. the long segment of this wave, if any ------------------------------------------------------
+    const u64 lmask = __ballot(is_long && vr.ok);
+    if (lmask) {
+      const u32 ll = static_cast<u32>(__ffsll(static_cast<long long>(lmask))) - 1u;
+      const u32 start = wave_base + ll;
+      const u32 lkey = static_cast<u32>(__builtin_amdgcn_readlane(key, ll));
+      const int gx = __builtin_amdgcn_readlane(vr.gx, ll), gy = __builtin_amdgcn_readlane(vr.gy, ll), gz = __builtin_amdgcn_readlane(vr.gz, ll);
+      const u64 pbits = reinterpret_cast<u64>(vr.ptr);
+      u32* vptr = reinterpret_cast<u32*>(static_cast<u64>(static_cast<u32>(__builtin_amdgcn_readlane(static_cast<u32>(pbits), ll))) |
+                                         (static_cast<u64>(static_cast<u32>(__builtin_amdgcn_readlane(static_cast<u32>(pbits >> 32), ll))) << 32));
+      Voxel lv{__uint_as_float(vptr[0]), __uint_as_float(vptr[1]), vptr[2]};
+      for (u32 base = start;; base += 64) {
+        const u32 j = base + lane;
+        const bool inl = (j < n) && (rec_key[j] == lkey);
+        float s2 = 0.0f, u2 = 0.0f;
+        u32 c2 = 0;
+        bool sat = false;
+        if (inl) {
+          const u32 r = rec_ray[j];
+          const F3 pg{R.px[r], R.py[r], R.pz[r]};
+          s2 = compute_sdf(P, pg, gx, gy, gz);
+          u2 = update_weight(P, s2, R.w[r]);
+          c2 = R.color[r];
+          sat = saturating_update(P, s2, u2);
+        }
+        const u64 in_mask = __ballot(inl);
+        const u32 cnt_in = static_cast<u32>(__popcll(in_mask));  // contiguous: lanes [0, cnt_in)
+        if (cnt_in == 0) break;
+        const bool all_sat = __ballot(inl && sat) == in_mask;
+        if (all_sat && lv.d == P.trunc) {
+          // distance provably stays at +trunc; only the weight moves
+          const bool unit = __ballot(inl && u2 == 1.0f) == in_mask;
+          if (lv.w >= P.max_weight) {
+            // min(max_weight, w + u) == max_weight for every u > 0
+          } else if (unit && lv.w == truncf(lv.w) && lv.w + static_cast<float>(cnt_in) < 16777216.0f) {
+            lv.w = std_min(P.max_weight, lv.w + static_cast<float>(cnt_in));  // integers add exactly
+          } else {
+            for (u32 k = 0; k < cnt_in; ++k) {
+              const float nw = lv.w + readlane_f32(u2, k);
+              if (!(nw < kEps)) lv.w = std_min(P.max_weight, nw);
+            }
+          }
+        } else {
+          for (u32 k = 0; k < cnt_in; ++k) update_voxel(P, lv, readlane_f32(s2, k), readlane_f32(u2, k), static_cast<u32>(__builtin_amdgcn_readlane(c2, k)));
+        }
+        if (cnt_in < 64) break;
+      }
+      if (lane == 0) {
+        vptr[0] = __float_as_uint(lv.d);
+        vptr[1] = __float_as_uint(lv.w);
+        vptr[2] = lv.c;
+      }
+    }
+    // ---- frame statistics ------------------------------------------------------------------------------
+    const u64 vmask = __ballot(valid), hmask = __ballot(head);
+    if (lane == 0) {
+      atomicAdd(&blk_updates, static_cast<u32>(__popcll(vmask)));
+      atomicAdd(&blk_voxels, static_cast<u32>(__popcll(hmask)));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (blk_updates) atomicAdd(&cnt->n_updates, blk_updates);
+    if (blk_voxels) atomicAdd(&cnt->n_short, blk_voxels);  // n_short + n_long = touched voxels
   }
 }
 
@@ -829,13 +871,13 @@ struct cox_integrator {
   // record-sized workspace
   u32 rcap = 0;
   u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
-  u32 *short_start = nullptr, *short_len = nullptr, *long_start = nullptr;
   u32* touched_slots = nullptr;  // [layer capacity]
   SortWorkspace sortws;
   u32 sort_counts_cap = 0, scan_sums_cap = 0;
   Counters* d_cnt = nullptr;
   Counters* h_cnt = nullptr;  // pinned
   cox_frame_stats last{};
+  bool final_counts_pending = false;  // the frame issued its end-of-frame counter copy
   u32 last_err = 0;
   // timing of the apply kernels (bench roofline)
   bool profiling = false;
@@ -913,9 +955,6 @@ static int ensure_record_capacity(cox_integrator* I, u64 n) {
     COX_TRY(dev_realloc(&I->rec_key[k], cap));
     COX_TRY(dev_realloc(&I->rec_ray[k], cap));
   }
-  COX_TRY(dev_realloc(&I->short_start, cap));
-  COX_TRY(dev_realloc(&I->short_len, cap));
-  COX_TRY(dev_realloc(&I->long_start, cap / 64 + 64));
   I->rcap = cap;
   return ensure_sort_ws(I, std::max(I->pcap, I->rcap));
 }
@@ -965,6 +1004,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   COX_HIP(hipMemsetAsync(I->d_cnt, 0, sizeof(Counters), s));
   I->last = cox_frame_stats{};
   I->last.n_points = n;
+  I->final_counts_pending = false;
   if (n == 0) return COX_OK;
 
   u32 n_rays_max = n;
@@ -983,7 +1023,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
     exclusive_scan_u32(I->head, I->head, nullptr, n, &I->d_cnt->n_rays, I->sortws.scan, s);
     hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, n, sk, I->head, I->bstart);
-    hipLaunchKernelGGL(k_bundle_merge, grid_for(n), dim3(256), 0, s, P, np2, xyz, rgba, sk, sv, I->bstart, R, I->d_cnt);
+    hipLaunchKernelGGL(k_bundle_merge, dim3(std::min<u32>(2048, std::max<u32>(1, (n + 255) / 256))), dim3(256), 0, s, P, np2, xyz, rgba, sk, sv, I->bstart, R, I->d_cnt);
   } else {
     hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, P, xyz, rgba, R, I->d_cnt);
   }
@@ -1000,6 +1040,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   I->last.n_rays = I->h_cnt->n_rays;
   I->last.n_touched_blocks = n_touched;
   I->last.n_new_blocks = I->h_cnt->n_new_blocks;
+  I->last_err |= I->h_cnt->err;
   if (n_rec == 0) return COX_OK;
   COX_TRY(ensure_record_capacity(I, n_rec));
   hipLaunchKernelGGL(k_emit, grid_for(n_rays_max), dim3(256), 0, s, P, R, n_rays_max, L, I->rec_key[0], I->rec_ray[0], I->rcap, I->d_cnt, I->fh_keys,
@@ -1008,31 +1049,30 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   const int cur = radix_sort_pairs(I->rec_key[0], I->rec_ray[0], I->rec_key[1], I->rec_ray[1], &I->d_cnt->n_records, n_rec, vbits, I->sortws, s);
   const u32* rk = I->rec_key[cur];
   const u32* rr = I->rec_ray[cur];
-  hipLaunchKernelGGL(k_segments, grid_for(n_rec), dim3(256), 0, s, rk, &I->d_cnt->n_records, I->short_start, I->short_len, I->long_start, I->d_cnt);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->profiling) {
     COX_HIP(hipEventCreate(&e0));
     COX_HIP(hipEventCreate(&e1));
     COX_HIP(hipEventRecord(e0, s));
   }
-  const u32 apply_blocks = std::min<u32>(4096, std::max<u32>(1, (n_rec + 255) / 256));
-  hipLaunchKernelGGL(k_apply_short, dim3(apply_blocks), dim3(256), 0, s, P, R, L, I->touched_slots, rk, rr, I->short_start, I->short_len, I->d_cnt);
-  hipLaunchKernelGGL(k_apply_long, dim3(std::min<u32>(4096, std::max<u32>(1, n_rec / 64 / 4 + 1))), dim3(256), 0, s, P, R, L, I->touched_slots, rk, rr,
-                     &I->d_cnt->n_records, I->long_start, I->d_cnt);
+  hipLaunchKernelGGL(k_apply, grid_for(n_rec), dim3(256), 0, s, P, R, L, I->touched_slots, rk, rr, &I->d_cnt->n_records, I->d_cnt);
   if (I->profiling) {
     COX_HIP(hipEventRecord(e1, s));
     I->apply_events.emplace_back(e0, e1);
   }
   COX_HIP(hipMemcpyAsync(I->h_cnt, I->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  I->final_counts_pending = true;
   COX_HIP(hipGetLastError());
   return COX_OK;
 }
 
 static int integrator_finish_frame(cox_integrator* I) {
   COX_HIP(hipStreamSynchronize(I->stream));
-  I->last.n_updates = I->h_cnt->n_updates;
-  I->last.n_touched_voxels = static_cast<uint64_t>(I->h_cnt->n_short) + I->h_cnt->n_long;
-  I->last_err |= I->h_cnt->err;
+  if (I->final_counts_pending) {
+    I->last.n_updates = I->h_cnt->n_updates;
+    I->last.n_touched_voxels = static_cast<uint64_t>(I->h_cnt->n_short) + I->h_cnt->n_long;
+    I->last_err |= I->h_cnt->err;
+  }
   u32 lerr = 0;
   COX_HIP(hipMemcpy(&lerr, I->layer->d_err, sizeof(u32), hipMemcpyDeviceToHost));
   I->last_err |= lerr;
@@ -1054,6 +1094,7 @@ static int integrator_finish_frame(cox_integrator* I) {
 extern "C" {
 
 int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out) {
+  COX_ENTRY();
   if (!layer || !cfg || !out) return COX_ERR_INVALID_ARG;
   if (method != COX_METHOD_SIMPLE && method != COX_METHOD_MERGED) return (method == COX_METHOD_FAST) ? COX_ERR_UNSUPPORTED : COX_ERR_INVALID_ARG;
   if (cfg->integration_order_mode != 0) return COX_ERR_UNSUPPORTED;
@@ -1091,7 +1132,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   }
   void* ptrs[] = {I->rays.px, I->rays.py, I->rays.pz, I->rays.w, I->rays.color, I->rays.flags, I->rays.key, I->rays.nsteps, I->rays.rec_off, I->pslot,
                   I->skey[0], I->skey[1], I->sval[0], I->sval[1], I->head, I->bstart, I->fh_keys, I->fh_first, I->own_xyz, I->own_rgba, I->depth_flag,
-                  I->rec_key[0], I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->short_start, I->short_len, I->long_start, I->touched_slots,
+                  I->rec_key[0], I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->touched_slots,
                   I->sortws.counts, I->sortws.scan.block_sums, I->d_cnt};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1101,12 +1142,14 @@ void cox_integrator_destroy(cox_integrator_t* I) {
 }
 
 int cox_integrate_points_dev(cox_integrator_t* I, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace) {
+  COX_ENTRY();
   if (!I || !T_G_C || (n && !xyz_dev) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   return integrate_device(I, T_G_C, xyz_dev, rgba_dev, static_cast<u32>(n), freespace);
 }
 
 int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
+  COX_ENTRY();
   if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   COX_TRY(ensure_point_capacity(I, static_cast<u32>(n)));
@@ -1119,6 +1162,7 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
 }
 
 int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4]) {
+  COX_ENTRY();
   if (!I || !T_G_C || !depth_dev || !K || w <= 0 || h <= 0 || static_cast<uint64_t>(w) * h > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
@@ -1136,28 +1180,34 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
 }
 
 int cox_integrator_sync(cox_integrator_t* I) {
+  COX_ENTRY();
   if (!I) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   return integrator_finish_frame(I);
 }
 
 int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
+  COX_ENTRY();
   if (!I || !stats) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   COX_HIP(hipStreamSynchronize(I->stream));
-  I->last.n_updates = I->h_cnt->n_updates;
-  I->last.n_touched_voxels = static_cast<uint64_t>(I->h_cnt->n_short) + I->h_cnt->n_long;
+  if (I->final_counts_pending) {
+    I->last.n_updates = I->h_cnt->n_updates;
+    I->last.n_touched_voxels = static_cast<uint64_t>(I->h_cnt->n_short) + I->h_cnt->n_long;
+  }
   *stats = I->last;
   return COX_OK;
 }
 
 int cox_integrator_set_profiling(cox_integrator_t* I, int on) {
+  COX_ENTRY();
   if (!I) return COX_ERR_INVALID_ARG;
   I->profiling = on != 0;
   return COX_OK;
 }
 
 int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* apply_launches, int reset) {
+  COX_ENTRY();
   if (!I) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   int st = integrator_finish_frame(I);

@@ -20,3 +20,17 @@ struct cox_layer {
   u32* d_err = nullptr;       // sticky device error bits
   u32 frame_id = 0;           // shared by every integrator on this layer
 };
+
+// hipGetLastError() is a per-thread sticky slot shared with every other HIP user in the process
+// (PyTorch probes peers / devices during its lazy init and may leave a benign error behind).  Every
+// entry point clears it first so that the check after our own launches only sees our own errors.
+#include <cstdio>
+#include <cstdlib>
+static inline void cox_clear_stale_hip_error(const char* where) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    static const bool verbose = std::getenv("COX_DEBUG") != nullptr;
+    if (verbose) fprintf(stderr, "[coxgraph_hip] %s: cleared stale HIP error left by an earlier call: %s\n", where, hipGetErrorString(e));
+  }
+}
+#define COX_ENTRY() cox_clear_stale_hip_error(__func__)

@@ -345,6 +345,7 @@ static int stage_samples(cox_reg* G, const uint32_t* sample_idx, uint64_t n_res,
 extern "C" {
 
 int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, cox_regpoints_t** out) {
+  COX_ENTRY();
   if (!out || (n && !xyz_dist_weight) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return COX_ERR_NO_DEVICE;
@@ -375,6 +376,7 @@ void cox_regpoints_destroy(cox_regpoints_t* R) {
 }
 
 int cox_reg_create(const cox_regpoints_t* reference, const cox_layer_t* reading, const cox_reg_config* cfg, cox_reg_t** out) {
+  COX_ENTRY();
   if (!reference || !reading || !out) return COX_ERR_INVALID_ARG;
   const cox_layer* L = reinterpret_cast<const cox_layer*>(reading);
   if (L->device != reference->device) return COX_ERR_INVALID_ARG;  // exchange submaps first
@@ -410,6 +412,7 @@ void cox_reg_destroy(cox_reg_t* G) {
 
 int cox_reg_evaluate(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double* residuals,
                      double* jac_ref, double* jac_read) {
+  COX_ENTRY();
   if (!G || !pose_ref || !pose_read || n_res > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(G->reading->device));
   if (n_res == 0) return sample_idx || G->ref->n == 0 ? COX_OK : COX_ERR_INVALID_ARG;
@@ -446,6 +449,7 @@ int cox_reg_evaluate(cox_reg_t* G, const double pose_ref[4], const double pose_r
 
 int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double H[64],
                       double b[8], double* cost, uint64_t* n_corr) {
+  COX_ENTRY();
   if (!G || !pose_ref || !pose_read || !H || !b || !cost || n_res > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(G->reading->device));
   for (int i = 0; i < 64; ++i) H[i] = 0.0;
@@ -488,6 +492,7 @@ int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_
 }
 
 int cox_reg_kernel_time(cox_reg_t* G, double* ms, uint64_t* launches, int reset) {
+  COX_ENTRY();
   if (!G) return COX_ERR_INVALID_ARG;
   if (ms) *ms = G->ms;
   if (launches) *launches = G->launches;

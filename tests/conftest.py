@@ -47,3 +47,13 @@ def hip():
     """The HIP engine through the C ABI; no fallback."""
     import coxgraph_amd
     return coxgraph_amd.load_engine()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """On a GPU box let PyTorch create its HIP context before the engine does (the order bench.py uses)."""
+    if _gpu_available():
+        import torch
+        torch.cuda.init()
+        torch.zeros(1, device="cuda")
+    yield
