@@ -1,0 +1,1094 @@
+// MI355X (gfx950) TSDF integrator behind include/coxgraph_hip.h.
+//
+// Replaces the work of voxblox's TsdfIntegratorBase::integratePointCloud as coxgraph calls it
+// (coxgraph/include/coxgraph/map_comm/tsdf_recover.h:75).  Design: DESIGN.md.
+//
+// One frame = ~30 kernel launches on the integrator's stream and NO host round trip: every count a
+// later kernel needs (rays, records, touched blocks, sort key width) stays in device memory, the host
+// only supplies grid-size hints taken from earlier frames.
+//
+//   rays      simple: one ray per valid point, canonical order = voxblox "mixed" sequence number
+//             merged: points bundled by terminal voxel (frame hash + stable radix sort), one ray per
+//                     bundle, canonical order = (clearing?, first visit)
+//   lengths   every ray knows its step count in O(1) (L1 index distance) -> exclusive scan -> each ray
+//             owns a contiguous slice of the record array
+//   touch     rays walk their voxels, insert block keys in the layer hash (bump-allocating pool
+//             blocks) and give every block touched this frame a dense ordinal
+//   emit      rays walk again and write (ordinal<<12 | linear voxel, ray id) records, ray-major
+//   sort      stable radix sort by voxel id -> per voxel, records are in canonical ray order
+//   apply     per voxel: the running weighted-mean/clamp update in exactly that order
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "cox_internal.hpp"
+#include "cox_sort.hpp"
+
+using namespace cox;
+
+// =================================================================================================
+// device side
+// =================================================================================================
+struct Counters {  // per-frame device counters, zeroed at frame start
+  u32 n_valid;      // points that passed isPointValid
+  u32 n_rays;       // rays cast (simple: valid points, merged: bundles)
+  u32 n_ray_slots;  // ray ids in use, [0, n_ray_slots) (simple: n_points, merged: bundles)
+  u32 n_records;    // sum of ray step counts
+  u32 n_touched;    // blocks touched this frame
+  u32 n_voxels;     // distinct voxels updated
+  u32 n_updates;    // (ray, voxel) updates
+  u32 n_long;       // voxels whose record run spans more than one wave
+  u32 n_new_blocks;
+  u32 err;
+  u32 n_depth_points;
+  u32 pad;
+};
+
+struct LayerView {
+  u32* voxels;
+  u64* ht_keys;
+  u32* ht_vals;
+  u32* ht_stamp;
+  u32* ht_ord;
+  u64* block_keys;
+  u32* d_nblocks;
+  u32 ht_mask;
+  u32 capacity;
+};
+
+struct RayArrays {
+  float *px, *py, *pz, *w;  // point_G and (merged) weight of each ray
+  u32* color;               // wire-packed colour
+  u32* flags;               // bit0 valid, bit1 clearing
+  u64* key;                 // terminal voxel key (anti-grazing)
+  u32* nsteps;              // records this ray emits
+  u32* rec_off;             // exclusive scan of nsteps
+};
+
+// both ping-pong buffers of the record sort + where the result ended up
+struct RecordView {
+  const u32* key[2];
+  const u32* ray[2];
+  const SortInfo* info;
+  const u32* d_n;
+};
+
+__device__ __forceinline__ u32 pack_rgba_wire(const uint8_t* rgba, u32 i) {
+  if (!rgba) return 0u;
+  const u32 v = reinterpret_cast<const u32*>(rgba)[i];  // little endian: r | g<<8 | b<<16 | a<<24
+  return ((v >> 24) & 255u) | (((v >> 16) & 255u) << 8) | (((v >> 8) & 255u) << 16) | ((v & 255u) << 24);
+}
+__device__ __forceinline__ bool point_valid(const FrameParams& P, F3 p, bool* clearing) {
+  const float r = sqrtf(dot3(p, p));
+  if (r < P.min_ray) return false;
+  if (r > P.max_ray) {
+    if (P.allow_clear || P.freespace) {
+      *clearing = true;
+      return true;
+    }
+    return false;
+  }
+  *clearing = P.freespace != 0;
+  return true;
+}
+__device__ __forceinline__ float voxel_weight(const FrameParams& P, F3 p) {
+  if (P.use_const_weight) return 1.0f;
+  const float dz = fabsf(p.z);
+  if (dz > kEps) return 1.0f / (dz * dz);
+  return 0.0f;
+}
+__device__ __forceinline__ float readlane_f32(float v, u32 lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+
+// ---- simple: one ray per point, ray id = mixed-order sequence number --------------------------
+__global__ void __launch_bounds__(256) k_rays_simple(FrameParams P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba, RayArrays R,
+                                                     Counters* cnt) {
+  const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq == 0) cnt->n_ray_slots = P.n_points;
+  if (seq >= P.n_points) return;
+  const u32 idx = mixed_index(seq, P.n_points);
+  const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  bool clearing = false;
+  const bool valid = point_valid(P, p, &clearing);
+  u32 nsteps = 0, flags = 0;
+  if (valid) {
+    const F3 pg = transform_point(P, p);
+    Dda d;
+    dda_setup(d, P, pg, clearing);
+    if (d.range_error) atomicOr(&cnt->err, kErrRange);
+    nsteps = d.nsteps;
+    flags = 1u | (clearing ? 2u : 0u);
+    R.px[seq] = pg.x;
+    R.py[seq] = pg.y;
+    R.pz[seq] = pg.z;
+    R.w[seq] = voxel_weight(P, p);
+    R.color[seq] = pack_rgba_wire(rgba, idx);
+  }
+  R.flags[seq] = flags;
+  R.nsteps[seq] = nsteps;
+  const u64 m = __ballot(valid);
+  if (lane_id() == 0 && m) {
+    atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
+    atomicAdd(&cnt->n_rays, static_cast<u32>(__popcll(m)));
+  }
+}
+
+// ---- merged: bundle points by terminal voxel ---------------------------------------------------
+// thread = sequence number; inserts the terminal-voxel key in the per-frame hash and records the
+// first (smallest) sequence number of each bundle
+__global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const float* __restrict__ xyz, u64* __restrict__ fh_keys, u32* __restrict__ fh_first,
+                                                       u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
+  const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq >= P.n_points) return;
+  const u32 idx = mixed_index(seq, P.n_points);
+  const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  bool clearing = false;
+  bool valid = point_valid(P, p, &clearing);
+  u32 slot = kInvalid;
+  if (valid) {
+    const F3 pg = transform_point(P, p);
+    const float sx = pg.x * P.voxel_size_inv, sy = pg.y * P.voxel_size_inv, sz = pg.z * P.voxel_size_inv;
+    if (!(index_in_range(sx) && index_in_range(sy) && index_in_range(sz))) {  // also catches NaN
+      atomicOr(&cnt->err, kErrRange);
+      valid = false;
+    } else {
+      const u64 key = pack_key(grid_index(sx), grid_index(sy), grid_index(sz)) | (clearing ? (1ull << 63) : 0ull);
+      bool fresh;
+      slot = ht_insert(fh_keys, fh_mask, key, &fresh);
+      if (slot == kInvalid) {
+        atomicOr(&cnt->err, kErrTable);
+        valid = false;
+      } else if (__hip_atomic_load(&fh_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > seq) {
+        atomicMin(&fh_first[slot], seq);  // a stale (larger) value read above only costs this atomic
+      }
+    }
+  }
+  pslot[seq] = valid ? slot : kInvalid;
+  const u64 m = __ballot(valid);
+  if (lane_id() == 0 && m) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
+}
+// sort key of a point = (clearing ? np2 : 0) + first sequence number of its bundle; value = seq
+__global__ void __launch_bounds__(256) k_bundle_keys(u32 n, u32 np2, const u64* __restrict__ fh_keys, const u32* __restrict__ fh_first,
+                                                     const u32* __restrict__ pslot, u32* __restrict__ skey, u32* __restrict__ sval) {
+  const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq >= n) return;
+  const u32 slot = pslot[seq];
+  u32 k = kInvalid;
+  if (slot != kInvalid) k = fh_first[slot] + ((fh_keys[slot] >> 63) ? np2 : 0u);
+  skey[seq] = k;
+  sval[seq] = seq;
+}
+__global__ void __launch_bounds__(256) k_bundle_heads(u32 n, const u32* __restrict__ skey, u32* __restrict__ head) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 k = skey[i];
+  head[i] = (k != kInvalid && (i == 0 || skey[i - 1] != k)) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_bundle_starts(u32 n, const u32* __restrict__ skey, const u32* __restrict__ head_scan, u32* __restrict__ bstart,
+                                                       Counters* cnt) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) cnt->n_ray_slots = cnt->n_rays;  // n_rays = number of bundles, written by the scan before this kernel
+  if (i >= n) return;
+  const u32 k = skey[i];
+  if (k != kInvalid && (i == 0 || skey[i - 1] != k)) bstart[head_scan[i]] = i;
+}
+
+// wave = bundle: the sequential weighted mean of its points in visiting order, bit-exact with the
+// single-threaded reference loop
+//     merged = (merged * W + p * w) / (W + w);  colour = blend(colour, W, c, w);  W += w
+// 64 points at a time are gathered in parallel and everything that does not depend on the running
+// mean (W prefix, denominators, colour blend factors) is computed lane-parallel; the dependent chain
+// itself is split over lanes by role: lanes 0-2 carry x, y, z (one IEEE divide per step), lanes 3-6 the
+// four colour channels (multiply-add-round per step).
+__global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba,
+                                                      const u32* __restrict__ skey, const u32* __restrict__ sval, const u32* __restrict__ bstart,
+                                                      RayArrays R, Counters* cnt) {
+  const u32 n_bundles = cnt->n_rays;
+  const u32 n_valid = cnt->n_valid;
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nthreads = gridDim.x * blockDim.x;
+  const u32 lane = lane_id();
+  const bool is_pos = lane < 3;
+  const u32 shift = (lane >= 3 && lane < 7) ? 8u * (lane - 3u) : 0u;
+  for (u32 m = tid >> 6; m < n_bundles; m += nthreads >> 6) {
+    const u32 begin = bstart[m];
+    const u32 end = (m + 1 < n_bundles) ? bstart[m + 1] : n_valid;
+    const bool clearing = skey[begin] >= np2;
+    float val = 0.0f;  // this lane's component of the running mean / colour channel
+    float W = 0.0f;    // uniform
+    u64 key = 0;
+    bool done = false;
+    for (u32 base = begin; base < end && !done; base += 64) {
+      const u32 i = base + lane;
+      float px = 0.0f, py = 0.0f, pz = 0.0f, w = 0.0f;
+      u32 col = 0;
+      if (i < end) {
+        const u32 idx = mixed_index(sval[i], P.n_points);
+        px = xyz[3 * idx];
+        py = xyz[3 * idx + 1];
+        pz = xyz[3 * idx + 2];
+        w = voxel_weight(P, F3{px, py, pz});
+        col = pack_rgba_wire(rgba, idx);
+      }
+      if (base == begin) {
+        const F3 pg = transform_point(P, F3{readlane_f32(px, 0), readlane_f32(py, 0), readlane_f32(pz, 0)});
+        key = pack_key(grid_index(pg.x * P.voxel_size_inv), grid_index(pg.y * P.voxel_size_inv), grid_index(pg.z * P.voxel_size_inv));
+      }
+      const u32 cnt_in = min(64u, end - base);
+      // W before each point of the chunk (points with w < eps are skipped and leave W unchanged)
+      float Wpre;
+      const u64 in_mask = (cnt_in == 64) ? ~0ull : ((1ull << cnt_in) - 1ull);
+      if ((__ballot(w == 1.0f) & in_mask) == in_mask && W == truncf(W) && W < 8388608.0f) {
+        Wpre = W + static_cast<float>(lane);  // integers: every partial sum is exact
+      } else {
+        float run = W;
+        Wpre = W;
+        for (u32 k = 0; k < cnt_in; ++k) {
+          if (lane == k) Wpre = run;
+          const float wk = readlane_f32(w, k);
+          if (!(wk < kEps)) run += wk;
+        }
+      }
+      const float den = Wpre + w;
+      const float fa = Wpre / den, fb = w / den;  // colour blend factors of this point
+      for (u32 k = 0; k < cnt_in; ++k) {
+        const float w1 = readlane_f32(w, k);
+        if (w1 < kEps) continue;
+        const float Wk = readlane_f32(Wpre, k);
+        const u32 c1 = static_cast<u32>(__builtin_amdgcn_readlane(col, k));
+        const float x1 = readlane_f32(px, k), y1 = readlane_f32(py, k), z1 = readlane_f32(pz, k);
+        const float in = (lane == 0) ? x1 : (lane == 1) ? y1 : (lane == 2) ? z1 : static_cast<float>(static_cast<int>((c1 >> shift) & 255u));
+        if (is_pos) {
+          val = (val * Wk + in * w1) / readlane_f32(den, k);
+        } else {
+          val = roundf(val * readlane_f32(fa, k) + in * readlane_f32(fb, k));
+        }
+        W = Wk + w1;
+        if (clearing) {  // only the first point of a clearing bundle is used
+          done = true;
+          break;
+        }
+      }
+    }
+    const float mx = readlane_f32(val, 0), my = readlane_f32(val, 1), mz = readlane_f32(val, 2);
+    u32 mcolor = 0;
+#pragma unroll
+    for (u32 c = 0; c < 4; ++c) mcolor |= (static_cast<u32>(static_cast<int>(readlane_f32(val, 3 + c))) & 255u) << (8u * c);
+    if (lane == 0) {
+      const F3 pg = transform_point(P, F3{mx, my, mz});
+      Dda d;
+      dda_setup(d, P, pg, clearing);
+      if (d.range_error) atomicOr(&cnt->err, kErrRange);
+      R.px[m] = pg.x;
+      R.py[m] = pg.y;
+      R.pz[m] = pg.z;
+      R.w[m] = W;
+      R.color[m] = mcolor;
+      R.flags[m] = 1u | (clearing ? 2u : 0u);
+      R.key[m] = key;
+      R.nsteps[m] = d.nsteps;
+    }
+  }
+}
+
+// ---- touch: allocate blocks, give every block touched this frame a dense ordinal ---------------
+// anti-grazing (merged only): skip voxels that are the terminal voxel of another (non-clearing) bundle
+__device__ __forceinline__ bool grazing_skip(const FrameParams& P, const u64* fh_keys, u32 fh_mask, bool clearing, u64 own_key, int x, int y, int z) {
+  if (!P.anti_grazing) return false;
+  const u64 k = pack_key(x, y, z);
+  if (!clearing && k == own_key) return false;
+  return ht_find(fh_keys, fh_mask, k) != kInvalid;
+}
+
+__global__ void __launch_bounds__(256) k_touch(FrameParams P, RayArrays R, LayerView L, u32* __restrict__ touched_slots, Counters* cnt, u32* layer_err,
+                                               const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const u32 n_slots = cnt->n_ray_slots;
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_slots; r += gridDim.x * blockDim.x) {
+    const u32 ns = R.nsteps[r];
+    if (ns == 0) continue;
+    const bool clearing = (R.flags[r] & 2u) != 0;
+    const F3 pg{R.px[r], R.py[r], R.pz[r]};
+    const u64 own_key = P.anti_grazing ? R.key[r] : 0ull;
+    Dda d;
+    dda_setup(d, P, pg, clearing);
+    u64 last_bkey = kEmptyKey;
+    for (u32 s = 0; s < ns; ++s) {
+      const int x = d.c[0], y = d.c[1], z = d.c[2];
+      dda_step(d);
+      if (grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z)) continue;
+      const u64 bkey = pack_key(x >> 4, y >> 4, z >> 4);
+      if (bkey == last_bkey) continue;
+      last_bkey = bkey;
+      bool fresh;
+      const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
+      if (slot == kInvalid) {
+        atomicOr(layer_err, kErrTable);
+        continue;
+      }
+      if (fresh) {
+        const u32 pool = atomicAdd(L.d_nblocks, 1u);
+        if (pool < L.capacity) {
+          L.ht_vals[slot] = pool;  // read by later kernels only
+          L.block_keys[pool] = bkey;
+          atomicAdd(&cnt->n_new_blocks, 1u);
+        } else {
+          atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped
+        }
+      }
+      if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
+          atomicExch(&L.ht_stamp[slot], P.frame_id) != P.frame_id) {
+        const u32 ord = atomicAdd(&cnt->n_touched, 1u);
+        touched_slots[ord] = slot;
+        L.ht_ord[slot] = ord;
+      }
+    }
+  }
+}
+
+// ---- emit: (voxel id, ray id) records, ray-major ------------------------------------------------
+// voxel id = ordinal of the block within this frame << 12 | linear voxel index.  Also publishes the key
+// width the record sort needs.
+__global__ void __launch_bounds__(256) k_emit(FrameParams P, RayArrays R, LayerView L, u32* __restrict__ rec_key, u32* __restrict__ rec_ray, u32 rec_cap,
+                                              Counters* cnt, SortInfo* sort_info, const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const u32 n_slots = cnt->n_ray_slots;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
+    u32 bits = 12;
+    while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
+    const bool overflow = cnt->n_records > rec_cap;
+    sort_info->nbits = overflow ? 0u : bits;  // 0 bits: every sort pass exits at once
+    sort_info->parity = 0;
+    if (overflow) atomicOr(&cnt->err, kErrRecords);
+  }
+  if (cnt->n_records > rec_cap) return;  // frame dropped as a whole (reported at sync); never a partial update
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_slots; r += gridDim.x * blockDim.x) {
+    const u32 ns = R.nsteps[r];
+    if (ns == 0) continue;
+    const u32 off = R.rec_off[r];
+    const bool clearing = (R.flags[r] & 2u) != 0;
+    const F3 pg{R.px[r], R.py[r], R.pz[r]};
+    const u64 own_key = P.anti_grazing ? R.key[r] : 0ull;
+    Dda d;
+    dda_setup(d, P, pg, clearing);
+    u64 last_bkey = kEmptyKey;
+    u32 last_ord = kInvalid;
+    for (u32 s = 0; s < ns; ++s) {
+      const int x = d.c[0], y = d.c[1], z = d.c[2];
+      dda_step(d);
+      u32 vid = kInvalid;
+      if (!grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z)) {
+        const u64 bkey = pack_key(x >> 4, y >> 4, z >> 4);
+        if (bkey != last_bkey) {
+          last_bkey = bkey;
+          const u32 slot = ht_find(L.ht_keys, L.ht_mask, bkey);
+          last_ord = (slot != kInvalid && L.ht_vals[slot] != kInvalid) ? L.ht_ord[slot] : kInvalid;
+        }
+        if (last_ord != kInvalid) vid = (last_ord << 12) | static_cast<u32>((x & 15) | ((y & 15) << 4) | ((z & 15) << 8));
+      }
+      rec_key[off + s] = vid;
+      rec_ray[off + s] = r;
+    }
+  }
+}
+
+// ---- apply: per voxel, the running weighted-mean / clamp update in canonical ray order -----------------
+// After the stable sort the records of one voxel are contiguous ("segment") and in ray order.
+// k_apply_eval, one wave per 64 consecutive records:
+//   1. every lane evaluates its own record (voxel centre, sdf, update weight, colour) -- the costly,
+//      order-independent part -- fully in parallel;
+//   2. the head lane of every segment that ends inside the wave replays its records in order out of the
+//      neighbours' registers (__shfl), at most 63 dependent steps;
+//   3. a segment that crosses a wave boundary ("long": the few near-camera voxels that every ray crosses)
+//      is only summarised: per wave, for the piece at its front (continuing from the previous wave) and
+//      the piece at its back (starting here): record count, whether every record is a provable no-op on a
+//      voxel sitting at +trunc with an integer weight (saturating_update), and the weight sum.
+// k_apply_long, one wave per long segment: walks the piece summaries (64 pieces = 4096 records per load),
+//   folds runs of no-op pieces exactly and replays only the rest record by record.
+// No float atomics anywhere; the result is bit-reproducible and equals the sequential reference order.
+struct VoxelRef {
+  u32* ptr;  // 3 words
+  int gx, gy, gz;
+  bool ok;
+};
+__device__ __forceinline__ VoxelRef locate_voxel(const LayerView& L, const u32* touched_slots, u32 vid) {
+  VoxelRef v;
+  const u32 ord = vid >> 12, lin = vid & 4095u;
+  const u32 slot = touched_slots[ord];
+  const u32 pool = L.ht_vals[slot];
+  int bx, by, bz;
+  unpack_key(L.ht_keys[slot], &bx, &by, &bz);
+  v.gx = bx * 16 + static_cast<int>(lin & 15u);
+  v.gy = by * 16 + static_cast<int>((lin >> 4) & 15u);
+  v.gz = bz * 16 + static_cast<int>(lin >> 8);
+  v.ok = pool != kInvalid;
+  v.ptr = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + lin) * kWordsPerVoxel;
+  return v;
+}
+// summary word of a piece: bits 0..6 record count (0..64), bit 31 "foldable"
+constexpr u32 kPieceFoldable = 0x80000000u;
+// a record can be folded when it provably keeps distance == trunc and adds an integer weight
+__device__ __forceinline__ bool foldable_update(const FrameParams& P, float sdf, float uw) {
+  return saturating_update(P, sdf, uw) && uw == truncf(uw) && uw < 65536.0f;
+}
+
+__global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
+                                                    u32* __restrict__ piece_front, u32* __restrict__ piece_back, u32* __restrict__ piece_wsum,
+                                                    u32* __restrict__ long_start, Counters* cnt) {
+  __shared__ u32 blk_updates, blk_voxels;
+  if (threadIdx.x == 0) {
+    blk_updates = 0;
+    blk_voxels = 0;
+  }
+  __syncthreads();
+  const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
+  const u32 par = V.info->parity & 1u;
+  const u32* __restrict__ rec_key = V.key[par];
+  const u32* __restrict__ rec_ray = V.ray[par];
+  const u32 lane = lane_id();
+  const u32 n_waves = (n + 63) >> 6;
+  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
+  u32 my_updates = 0, my_voxels = 0;
+  for (u32 wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < n_waves; wv += waves_total) {
+    const u32 wave_base = wv << 6;
+    const u32 i = wave_base + lane;
+    const bool in = i < n;
+    const u32 key = in ? rec_key[i] : kInvalid;
+    const u32 prev = (in && i > 0) ? rec_key[i - 1] : ~key;
+    const bool valid = in && key != kInvalid;
+    const bool boundary = !in || (key != prev) || i == 0;
+    const bool head = valid && boundary;
+    // ---- 1. per-record evaluation --------------------------------------------------------------------
+    VoxelRef vr{nullptr, 0, 0, 0, false};
+    float sdf = 0.0f, uw = 0.0f;
+    u32 color = 0;
+    bool fold = false;
+    if (valid) {
+      vr = locate_voxel(L, touched_slots, key);
+      const u32 r = rec_ray[i];
+      const F3 pg{R.px[r], R.py[r], R.pz[r]};
+      sdf = compute_sdf(P, pg, vr.gx, vr.gy, vr.gz);
+      uw = update_weight(P, sdf, R.w[r]);
+      color = R.color[r];
+      fold = foldable_update(P, sdf, uw);
+    }
+    // ---- segment geometry -----------------------------------------------------------------------------
+    const u64 bmask = __ballot(boundary);
+    const u64 later = (lane == 63) ? 0ull : (bmask >> (lane + 1));
+    u32 len = 0;
+    bool is_long = false;
+    if (head) {
+      if (later) {
+        len = static_cast<u32>(__ffsll(static_cast<long long>(later)));
+      } else {
+        const u32 nxt = wave_base + 64;
+        if (nxt >= n || rec_key[nxt] != key)
+          len = min(nxt, n) - i;
+        else
+          is_long = true;
+      }
+    }
+    // ---- 2. short segments: head lanes replay their records in order ----------------------------------
+    const bool run_short = head && !is_long && vr.ok;
+    Voxel v{0.0f, 0.0f, 0u};
+    if (run_short) {
+      v.d = __uint_as_float(vr.ptr[0]);
+      v.w = __uint_as_float(vr.ptr[1]);
+      v.c = vr.ptr[2];
+    }
+    u32 max_len = run_short ? len : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(static_cast<int>(max_len), off, 64)));
+    for (u32 k = 0; k < max_len; ++k) {
+      const int src = static_cast<int>((lane + k) & 63u);
+      const float s_k = __shfl(sdf, src, 64);
+      const float u_k = __shfl(uw, src, 64);
+      const u32 c_k = static_cast<u32>(__shfl(static_cast<int>(color), src, 64));
+      if (run_short && k < len) update_voxel(P, v, s_k, u_k, c_k);
+    }
+    if (run_short) {
+      vr.ptr[0] = __float_as_uint(v.d);
+      vr.ptr[1] = __float_as_uint(v.w);
+      vr.ptr[2] = v.c;
+    }
+    // ---- 3. summaries of the pieces of long segments --------------------------------------------------
+    // front piece: lanes [0, e) that continue the previous wave's last segment (e = first boundary lane)
+    const u32 e = bmask ? static_cast<u32>(__ffsll(static_cast<long long>(bmask))) - 1u : 64u;
+    {
+      const u64 fmask = (e == 64) ? ~0ull : ((1ull << e) - 1ull);
+      const bool all_fold = (__ballot(fold) & fmask) == fmask;
+      const float wf = (lane < e) ? uw : 0.0f;
+      u32 wsum = all_fold ? static_cast<u32>(wf) : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) wsum += static_cast<u32>(__shfl_xor(static_cast<int>(wsum), off, 64));
+      if (lane == 0) {
+        piece_front[wv] = e | ((all_fold && e > 0) ? kPieceFoldable : 0u);
+        piece_wsum[2 * wv] = wsum;
+      }
+    }
+    // back piece: the long segment (at most one) that starts in this wave
+    const u64 lmask = __ballot(is_long);
+    if (lmask) {
+      const u32 ll = static_cast<u32>(__ffsll(static_cast<long long>(lmask))) - 1u;
+      const u64 bm = ~((1ull << ll) - 1ull);
+      const bool all_fold = (__ballot(fold) & bm) == bm;
+      const float wb = (lane >= ll) ? uw : 0.0f;
+      u32 wsum = all_fold ? static_cast<u32>(wb) : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) wsum += static_cast<u32>(__shfl_xor(static_cast<int>(wsum), off, 64));
+      if (lane == ll) {
+        piece_back[wv] = (64u - ll) | (all_fold ? kPieceFoldable : 0u);
+        piece_wsum[2 * wv + 1] = wsum;
+        long_start[atomicAdd(&cnt->n_long, 1u)] = i;
+      }
+    }
+    my_updates += static_cast<u32>(__popcll(__ballot(valid)));
+    my_voxels += static_cast<u32>(__popcll(__ballot(head)));
+  }
+  if (lane == 0) {
+    if (my_updates) atomicAdd(&blk_updates, my_updates);
+    if (my_voxels) atomicAdd(&blk_voxels, my_voxels);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (blk_updates) atomicAdd(&cnt->n_updates, blk_updates);
+    if (blk_voxels) atomicAdd(&cnt->n_voxels, blk_voxels);
+  }
+}
+
+// replay records [a, a + count) of the long segment in order (count <= 64)
+__device__ __forceinline__ void replay_piece(const FrameParams& P, const RayArrays& R, const u32* __restrict__ rec_ray, int gx, int gy, int gz, u32 a, u32 count,
+                                             u32 lane, Voxel& v) {
+  float s = 0.0f, u = 0.0f;
+  u32 c = 0;
+  if (lane < count) {
+    const u32 r = rec_ray[a + lane];
+    const F3 pg{R.px[r], R.py[r], R.pz[r]};
+    s = compute_sdf(P, pg, gx, gy, gz);
+    u = update_weight(P, s, R.w[r]);
+    c = R.color[r];
+  }
+  for (u32 k = 0; k < count; ++k) update_voxel(P, v, readlane_f32(s, k), readlane_f32(u, k), static_cast<u32>(__builtin_amdgcn_readlane(c, k)));
+}
+// fold a run of foldable pieces with total integer weight wsum; false when the voxel state does not allow it
+__device__ __forceinline__ bool fold_pieces(const FrameParams& P, Voxel& v, u32 wsum) {
+  if (v.d != P.trunc) return false;
+  if (v.w >= P.max_weight) return true;  // min(max_weight, w + u) == max_weight for every u > 0
+  if (v.w != truncf(v.w) || v.w + static_cast<float>(wsum) >= 16777216.0f) return false;
+  v.w = std_min(P.max_weight, v.w + static_cast<float>(wsum));  // integer partial sums are exact
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_apply_long(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
+                                                    const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
+                                                    const u32* __restrict__ piece_wsum, const u32* __restrict__ long_start, const Counters* cnt,
+                                                    u32* layer_err) {
+  // last kernel of the frame: make this frame's error bits sticky until the host next looks
+  if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
+  const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
+  const u32 n_long = n ? cnt->n_long : 0u;
+  const u32 par = V.info->parity & 1u;
+  const u32* __restrict__ rec_key = V.key[par];
+  const u32* __restrict__ rec_ray = V.ray[par];
+  const u32 lane = lane_id();
+  const u32 n_waves = (n + 63) >> 6;
+  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (u32 j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; j < n_long; j += waves_total) {
+    const u32 start = long_start[j];
+    const VoxelRef vr = locate_voxel(L, touched_slots, rec_key[start]);
+    if (!vr.ok) continue;
+    Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
+    const u32 w0 = start >> 6;
+    // the piece at the back of the wave that holds the head
+    {
+      const u32 pb = piece_back[w0];
+      const u32 count = pb & 127u;
+      if (!((pb & kPieceFoldable) && fold_pieces(P, v, piece_wsum[2 * w0 + 1]))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count, lane, v);
+    }
+    // front pieces of the following waves; the segment ends with the first piece shorter than 64
+    bool more = true;
+    for (u32 wbase = w0 + 1; more && wbase < n_waves; wbase += 64) {
+      const u32 w = wbase + lane;
+      const u32 pf = (w < n_waves) ? piece_front[w] : 0u;
+      const u32 ws = (w < n_waves) ? piece_wsum[2 * w] : 0u;
+      const u32 count = pf & 127u;
+      const u64 end_mask = __ballot(count < 64u);
+      const u32 n_use = end_mask ? static_cast<u32>(__ffsll(static_cast<long long>(end_mask))) : 64u;  // pieces [0, n_use) belong to the segment
+      if (end_mask) more = false;
+      const u64 use_mask = (n_use == 64) ? ~0ull : ((1ull << n_use) - 1ull);
+      const u64 hard_mask = __ballot(!(pf & kPieceFoldable)) & use_mask;  // pieces that need a record-by-record replay
+      u32 pos = 0;
+      while (pos < n_use) {
+        const u64 hard_from = hard_mask >> pos;
+        const u32 run = hard_from ? static_cast<u32>(__ffsll(static_cast<long long>(hard_from))) - 1u : (n_use - pos);  // foldable pieces ahead
+        if (run > 0) {
+          // total weight of pieces [pos, pos + run)
+          u32 t = (lane >= pos && lane < pos + run) ? ws : 0u;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) t += static_cast<u32>(__shfl_xor(static_cast<int>(t), off, 64));
+          if (fold_pieces(P, v, t)) {
+            pos += run;
+            continue;
+          }
+        }
+        // replay piece `pos` (hard, or the voxel is not in a foldable state yet)
+        const u32 cnt_p = static_cast<u32>(__builtin_amdgcn_readlane(count, pos));
+        if (cnt_p) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, (wbase + pos) << 6, cnt_p, lane, v);
+        pos += 1;
+      }
+    }
+    if (lane == 0) {
+      vr.ptr[0] = __float_as_uint(v.d);
+      vr.ptr[1] = __float_as_uint(v.w);
+      vr.ptr[2] = v.c;
+    }
+  }
+}
+
+// ---- depth front end ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_depth_flags(const float* __restrict__ depth, u32 n, u32* __restrict__ flag) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = depth[i];
+  flag[i] = (isfinite(d) && d > 0.0f) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ depth, const uint8_t* __restrict__ rgba, int w, int h, float fx, float fy,
+                                                      float cx, float cy, const u32* __restrict__ pos, float* __restrict__ xyz,
+                                                      uint8_t* __restrict__ rgba_out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
+  if (i >= n) return;
+  const float d = depth[i];
+  if (!(isfinite(d) && d > 0.0f)) return;
+  const u32 o = pos[i];
+  const u32 u = i % static_cast<u32>(w), v = i / static_cast<u32>(w);
+  const float xn = (static_cast<float>(u) - cx) / fx;
+  const float yn = (static_cast<float>(v) - cy) / fy;
+  xyz[3 * o] = d * xn;
+  xyz[3 * o + 1] = d * yn;
+  xyz[3 * o + 2] = d;
+  if (rgba_out) reinterpret_cast<u32*>(rgba_out)[o] = rgba ? reinterpret_cast<const u32*>(rgba)[i] : 0u;
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+constexpr int kStatRing = 8;
+
+struct cox_integrator {
+  cox_layer* layer = nullptr;
+  cox_tsdf_config cfg;
+  int method = 0;
+  hipStream_t stream = nullptr;
+  // point-sized workspace
+  u32 pcap = 0;
+  RayArrays rays{};
+  u32 *pslot = nullptr, *skey[2] = {nullptr, nullptr}, *sval[2] = {nullptr, nullptr}, *head = nullptr, *bstart = nullptr;
+  u64* fh_keys = nullptr;  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
+  u32* fh_first = nullptr;
+  u32 fh_cap = 0;
+  float* own_xyz = nullptr;  // staging for host / depth inputs
+  uint8_t* own_rgba = nullptr;
+  u32* depth_flag = nullptr;
+  // record-sized workspace
+  u32 rcap = 0;
+  u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
+  u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
+  u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr, *long_start = nullptr;
+  u32* touched_slots = nullptr;  // [layer ht_cap]
+  SortWorkspace sort_pts, sort_rec;
+  ScanWorkspace scanws;
+  u32 scan_cap = 0;
+  Counters* d_cnt = nullptr;
+  Counters* h_ring = nullptr;  // pinned, kStatRing entries
+  uint64_t frame_no = 0;       // frames enqueued
+  uint64_t counts_frame = 0;   // frame whose end-of-frame counters were last enqueued (0 = none)
+  cox_frame_stats last{};      // host-known part of the last frame's stats
+  bool last_has_counts = false;
+  u32 hint_records = 0, hint_rays = 0;
+  // timing of the apply kernels (bench roofline)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events;
+  double apply_ms = 0.0;
+  uint64_t apply_launches = 0;
+};
+
+template <typename T>
+static int dev_realloc(T** p, size_t count) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  if (count == 0) return COX_OK;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return (e == hipErrorOutOfMemory) ? COX_ERR_OUT_OF_MEMORY : COX_ERR_NO_DEVICE;
+  }
+  return COX_OK;
+}
+#define COX_TRY(expr)              \
+  do {                             \
+    int st_ = (expr);              \
+    if (st_ != COX_OK) return st_; \
+  } while (0)
+
+static int alloc_sort_ws(SortWorkspace* ws, u64 capacity) {
+  ws->tiles_cap = std::max<u32>(1, sort_num_tiles(capacity));
+  COX_TRY(dev_realloc(&ws->counts, static_cast<size_t>(ws->tiles_cap) * (1u << 11)));
+  if (!ws->totals) COX_TRY(dev_realloc(&ws->totals, static_cast<size_t>(kRsMaxPasses) * (1u << 11)));
+  if (!ws->info) {
+    COX_TRY(dev_realloc(&ws->info, 1));
+    COX_HIP(hipMemset(ws->info, 0, sizeof(SortInfo)));
+  }
+  return COX_OK;
+}
+
+// upper bound of ray_length_in_steps + 1 for any ray this configuration can cast
+static u32 max_steps_per_ray(const cox_integrator* I) {
+  const double reach = static_cast<double>(I->cfg.max_ray_length_m) + static_cast<double>(I->cfg.default_truncation_distance);
+  const double per_axis = std::floor(reach / static_cast<double>(I->layer->voxel_size)) + 3.0;
+  const double s = 3.0 * per_axis + 1.0;
+  return static_cast<u32>(std::min(s, 1.0e6));
+}
+
+static int ensure_capacity(cox_integrator* I, u32 n) {
+  if (n <= I->pcap) return COX_OK;
+  COX_HIP(hipStreamSynchronize(I->stream));
+  const u32 cap = std::max<u32>(n, 1024);
+  COX_TRY(dev_realloc(&I->rays.px, cap));
+  COX_TRY(dev_realloc(&I->rays.py, cap));
+  COX_TRY(dev_realloc(&I->rays.pz, cap));
+  COX_TRY(dev_realloc(&I->rays.w, cap));
+  COX_TRY(dev_realloc(&I->rays.color, cap));
+  COX_TRY(dev_realloc(&I->rays.flags, cap));
+  COX_TRY(dev_realloc(&I->rays.key, cap));
+  COX_TRY(dev_realloc(&I->rays.nsteps, cap));
+  COX_TRY(dev_realloc(&I->rays.rec_off, cap));
+  COX_TRY(dev_realloc(&I->pslot, cap));
+  for (int k = 0; k < 2; ++k) {
+    COX_TRY(dev_realloc(&I->skey[k], cap));
+    COX_TRY(dev_realloc(&I->sval[k], cap));
+  }
+  COX_TRY(dev_realloc(&I->head, cap));
+  COX_TRY(dev_realloc(&I->bstart, cap));
+  COX_TRY(dev_realloc(&I->own_xyz, static_cast<size_t>(cap) * 3));
+  COX_TRY(dev_realloc(&I->own_rgba, static_cast<size_t>(cap) * 4));
+  COX_TRY(dev_realloc(&I->depth_flag, cap));
+  I->fh_cap = next_pow2(2ull * cap);
+  COX_TRY(dev_realloc(&I->fh_keys, static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
+  I->fh_first = reinterpret_cast<u32*>(I->fh_keys + I->fh_cap);
+  COX_TRY(alloc_sort_ws(&I->sort_pts, cap));
+  // records: the worst case (every ray at maximum length) always fits, so a frame can never overflow
+  // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
+  I->steps_max = max_steps_per_ray(I);
+  const u64 want = static_cast<u64>(cap) * I->steps_max;
+  const u64 limit = 0x7FFFFFF0ull;
+  const u32 rcap = static_cast<u32>(std::min(want, limit));
+  for (int k = 0; k < 2; ++k) {
+    COX_TRY(dev_realloc(&I->rec_key[k], rcap));
+    COX_TRY(dev_realloc(&I->rec_ray[k], rcap));
+  }
+  const u32 wave_cap = rcap / 64 + 2;
+  COX_TRY(dev_realloc(&I->piece_front, wave_cap));
+  COX_TRY(dev_realloc(&I->piece_back, wave_cap));
+  COX_TRY(dev_realloc(&I->piece_wsum, static_cast<size_t>(wave_cap) * 2));
+  COX_TRY(dev_realloc(&I->long_start, wave_cap));
+  COX_TRY(alloc_sort_ws(&I->sort_rec, rcap));
+  const u32 need_scan = scan_num_blocks(cap) + 2;
+  if (need_scan > I->scan_cap) {
+    COX_TRY(dev_realloc(&I->scanws.block_sums, need_scan));
+    I->scan_cap = need_scan;
+  }
+  I->rcap = rcap;
+  I->pcap = cap;
+  return COX_OK;
+}
+
+static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n, int freespace) {
+  const cox_tsdf_config& c = I->cfg;
+  FrameParams P;
+  P.qw = T[0];
+  P.qx = T[1];
+  P.qy = T[2];
+  P.qz = T[3];
+  P.tx = T[4];
+  P.ty = T[5];
+  P.tz = T[6];
+  P.voxel_size = I->layer->voxel_size;
+  P.voxel_size_inv = I->layer->voxel_size_inv;
+  P.trunc = c.default_truncation_distance;
+  P.max_weight = c.max_weight;
+  P.min_ray = c.min_ray_length_m;
+  P.max_ray = c.max_ray_length_m;
+  P.sparsity_factor = c.sparsity_compensation_factor;
+  P.start_subsampling_inv = c.start_voxel_subsampling_factor * I->layer->voxel_size_inv;
+  P.n_points = n;
+  P.frame_id = 0;
+  P.use_const_weight = c.use_const_weight;
+  P.allow_clear = c.allow_clear;
+  P.carving = c.voxel_carving_enabled;
+  P.use_dropoff = c.use_weight_dropoff;
+  P.use_sparsity = c.use_sparsity_compensation_factor;
+  P.anti_grazing = (I->method == COX_METHOD_MERGED) ? c.enable_anti_grazing : 0;
+  P.freespace = freespace;
+  P.cast_from_origin = 1;
+  return P;
+}
+
+static inline dim3 grid_for(u32 n, u32 block = 256, u32 cap = 0x7FFFFFFFu) { return dim3(std::min<u32>(cap, std::max<u32>(1, (n + block - 1) / block))); }
+
+// Refresh the grid-size hints from the newest end-of-frame counters that have certainly landed.  The
+// hints never affect results (every kernel grid-strides over device-side counts), only occupancy.
+static void refresh_hints(cox_integrator* I) {
+  if (I->counts_frame == 0) return;
+  const Counters& c = I->h_ring[(I->counts_frame) % kStatRing];  // may be one frame stale or mid-copy: harmless
+  const u32 rec = c.n_records, rays = c.n_ray_slots;
+  if (rec) I->hint_records = std::max<u32>(rec + rec / 4 + 65536, I->hint_records / 2);
+  if (rays) I->hint_rays = std::max<u32>(rays + rays / 4 + 1024, I->hint_rays / 2);
+}
+
+// enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the stream reaches
+// the end of the frame
+static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
+  cox_layer* Lh = I->layer;
+  hipStream_t s = I->stream;
+  COX_TRY(ensure_capacity(I, n));
+  FrameParams P = make_params(I, T, n, freespace);
+  P.frame_id = ++Lh->frame_id;
+  LayerView L{Lh->voxels, Lh->ht_keys, Lh->ht_vals, Lh->ht_stamp, Lh->ht_ord, Lh->block_keys, Lh->d_nblocks, Lh->ht_cap - 1, static_cast<u32>(Lh->capacity)};
+  RayArrays R = I->rays;
+  Counters* C = I->d_cnt;
+  COX_HIP(hipMemsetAsync(C, 0, sizeof(Counters), s));
+  I->frame_no += 1;
+  I->last = cox_frame_stats{};
+  I->last.n_points = n;
+  I->last_has_counts = false;
+  if (n == 0) return COX_OK;
+  refresh_hints(I);
+
+  const u32 fh_mask = I->fh_cap - 1;
+  const bool merged = I->method == COX_METHOD_MERGED;
+  u32 ray_hint;
+  if (merged) {
+    const u32 np2 = next_pow2(static_cast<u64>(n) + 1);
+    COX_HIP(hipMemsetAsync(I->fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
+    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, P, xyz, I->fh_keys, I->fh_first, fh_mask, I->pslot, C);
+    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, n, np2, I->fh_keys, I->fh_first, I->pslot, I->skey[0], I->sval[0]);
+    const int kbits = ceil_log2(np2) + 1;  // + clearing bit; kInvalid's low bits exceed every valid key
+    const int cur = radix_sort_pairs<11>(I->skey[0], I->sval[0], I->skey[1], I->sval[1], nullptr, n, n, kbits, false, 0, I->sort_pts, s);
+    const u32* sk = I->skey[cur];
+    const u32* sv = I->sval[cur];
+    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, s, n, sk, I->head);
+    // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
+    exclusive_scan_u32(I->head, I->head, nullptr, n, n, &C->n_rays, I->scanws, s);
+    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, n, sk, I->head, I->bstart, C);
+    ray_hint = I->hint_rays ? std::min(I->hint_rays, n) : std::min<u32>(n, 16384);
+    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s, P, np2, xyz, rgba, sk, sv, I->bstart, R, C);
+  } else {
+    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, P, xyz, rgba, R, C);
+    ray_hint = n;
+  }
+  // record offsets over the ray slots in use
+  exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws, s);
+  // allocate + stamp blocks, then emit records
+  hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->touched_slots, C, Lh->d_err, I->fh_keys, fh_mask);
+  hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->rec_key[0], I->rec_ray[0], I->rcap, C, I->sort_rec.info, I->fh_keys,
+                     fh_mask);
+  const u32 rec_hint = I->hint_records ? std::min(I->hint_records, I->rcap) : std::min<u32>(I->rcap, std::max<u32>(1u << 20, n * 4u));
+  // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits
+  (void)radix_sort_pairs<11>(I->rec_key[0], I->rec_ray[0], I->rec_key[1], I->rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, s);
+  RecordView V{{I->rec_key[0], I->rec_key[1]}, {I->rec_ray[0], I->rec_ray[1]}, I->sort_rec.info, &C->n_records};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (I->profiling) {
+    COX_HIP(hipEventCreate(&e0));
+    COX_HIP(hipEventCreate(&e1));
+    COX_HIP(hipEventRecord(e0, s));
+  }
+  hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum,
+                     I->long_start, C);
+  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum, I->long_start, C,
+                     Lh->d_err);
+  if (I->profiling) {
+    COX_HIP(hipEventRecord(e1, s));
+    I->apply_events.emplace_back(e0, e1);
+  }
+  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], C, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  I->counts_frame = I->frame_no;
+  I->last_has_counts = true;
+  COX_HIP(hipGetLastError());
+  return COX_OK;
+}
+
+// wait for the stream, fold the last frame's counters into the stats, return deferred errors
+static int integrator_finish(cox_integrator* I) {
+  COX_HIP(hipStreamSynchronize(I->stream));
+  u32 err = 0;
+  if (I->last_has_counts) {
+    const Counters& c = I->h_ring[I->frame_no % kStatRing];
+    I->last.n_valid = c.n_valid;
+    I->last.n_rays = c.n_rays;
+    I->last.n_updates = c.n_updates;
+    I->last.n_touched_voxels = c.n_voxels;
+    I->last.n_touched_blocks = c.n_touched;
+    I->last.n_new_blocks = c.n_new_blocks;
+    if (c.n_records) I->hint_records = std::max<u32>(I->hint_records, c.n_records + c.n_records / 4 + 65536);
+  }
+  // errors of every frame since the last sync are sticky in the layer's device error word; report them once
+  u32 lerr = 0;
+  COX_HIP(hipMemcpy(&lerr, I->layer->d_err, sizeof(u32), hipMemcpyDeviceToHost));
+  if (lerr) COX_HIP(hipMemset(I->layer->d_err, 0, sizeof(u32)));
+  err |= lerr;
+  for (auto& ev : I->apply_events) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      I->apply_ms += ms;
+      I->apply_launches += 1;
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  I->apply_events.clear();
+  return err_bits_to_status(err);
+}
+
+extern "C" {
+
+int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out) {
+  COX_ENTRY();
+  if (!layer || !cfg || !out) return COX_ERR_INVALID_ARG;
+  if (method != COX_METHOD_SIMPLE && method != COX_METHOD_MERGED) return (method == COX_METHOD_FAST) ? COX_ERR_UNSUPPORTED : COX_ERR_INVALID_ARG;
+  if (cfg->integration_order_mode != 0) return COX_ERR_UNSUPPORTED;
+  if (!(cfg->default_truncation_distance > 0.0f) || !(cfg->max_weight > 0.0f) || !(cfg->max_ray_length_m > 0.0f)) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(layer->device));
+  cox_integrator* I = new (std::nothrow) cox_integrator();
+  if (!I) return COX_ERR_OUT_OF_MEMORY;
+  I->layer = layer;
+  I->cfg = *cfg;
+  I->method = method;
+  int st = COX_OK;
+  if (hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  if (st == COX_OK && hipMalloc(reinterpret_cast<void**>(&I->d_cnt), sizeof(Counters)) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
+    st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK) st = dev_realloc(&I->touched_slots, layer->ht_cap);  // one entry per block key the table can hold
+  if (st == COX_OK) {
+    memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
+    st = ensure_capacity(I, 640 * 480);
+  }
+  if (st != COX_OK) {
+    cox_integrator_destroy(I);
+    return st;
+  }
+  *out = I;
+  return COX_OK;
+}
+
+void cox_integrator_destroy(cox_integrator_t* I) {
+  if (!I) return;
+  (void)hipSetDevice(I->layer->device);
+  if (I->stream) (void)hipStreamSynchronize(I->stream);
+  for (auto& ev : I->apply_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  void* ptrs[] = {I->rays.px, I->rays.py, I->rays.pz, I->rays.w, I->rays.color, I->rays.flags, I->rays.key, I->rays.nsteps, I->rays.rec_off, I->pslot,
+                  I->skey[0], I->skey[1], I->sval[0], I->sval[1], I->head, I->bstart, I->fh_keys, I->own_xyz, I->own_rgba, I->depth_flag, I->rec_key[0],
+                  I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->piece_front, I->piece_back, I->piece_wsum, I->long_start, I->touched_slots,
+                  I->sort_pts.counts, I->sort_pts.totals, I->sort_pts.info, I->sort_rec.counts, I->sort_rec.totals, I->sort_rec.info, I->scanws.block_sums,
+                  I->d_cnt};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (I->h_ring) (void)hipHostFree(I->h_ring);
+  if (I->stream) (void)hipStreamDestroy(I->stream);
+  delete I;
+}
+
+int cox_integrate_points_dev(cox_integrator_t* I, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace) {
+  COX_ENTRY();
+  if (!I || !T_G_C || (n && !xyz_dev) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  return integrate_device(I, T_G_C, xyz_dev, rgba_dev, static_cast<u32>(n), freespace);
+}
+
+int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
+  COX_ENTRY();
+  if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
+  COX_HIP(hipStreamSynchronize(I->stream));  // the staging buffers may still feed an earlier frame
+  if (n) {
+    COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->stream));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->stream));
+  }
+  COX_TRY(integrate_device(I, T_G_C, I->own_xyz, rgba ? I->own_rgba : nullptr, static_cast<u32>(n), freespace));
+  return integrator_finish(I);
+}
+
+int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4]) {
+  COX_ENTRY();
+  if (!I || !T_G_C || !depth_dev || !K || w <= 0 || h <= 0 || static_cast<uint64_t>(w) * h > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
+  COX_TRY(ensure_capacity(I, n));
+  hipStream_t s = I->stream;
+  COX_HIP(hipStreamSynchronize(s));  // staging buffers
+  hipLaunchKernelGGL(k_depth_flags, grid_for(n), dim3(256), 0, s, depth_dev, n, I->depth_flag);
+  exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, &I->d_cnt->n_depth_points, I->scanws, s);
+  hipLaunchKernelGGL(k_depth_points, grid_for(n), dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz,
+                     I->own_rgba);
+  // the point count feeds the "mixed" visiting order, which is a function of N: it has to reach the host
+  Counters* tmp = &I->h_ring[0];
+  COX_HIP(hipMemcpyAsync(&tmp->n_depth_points, &I->d_cnt->n_depth_points, sizeof(u32), hipMemcpyDeviceToHost, s));
+  COX_HIP(hipStreamSynchronize(s));
+  const u32 n_pts = tmp->n_depth_points;
+  return integrate_device(I, T_G_C, I->own_xyz, I->own_rgba, n_pts, 0);
+}
+
+int cox_integrator_sync(cox_integrator_t* I) {
+  COX_ENTRY();
+  if (!I) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  return integrator_finish(I);
+}
+
+int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
+  COX_ENTRY();
+  if (!I || !stats) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  COX_HIP(hipStreamSynchronize(I->stream));
+  if (I->last_has_counts) {
+    const Counters& c = I->h_ring[I->frame_no % kStatRing];
+    I->last.n_valid = c.n_valid;
+    I->last.n_rays = c.n_rays;
+    I->last.n_updates = c.n_updates;
+    I->last.n_touched_voxels = c.n_voxels;
+    I->last.n_touched_blocks = c.n_touched;
+    I->last.n_new_blocks = c.n_new_blocks;
+  }
+  *stats = I->last;
+  return COX_OK;
+}
+
+int cox_integrator_set_profiling(cox_integrator_t* I, int on) {
+  COX_ENTRY();
+  if (!I) return COX_ERR_INVALID_ARG;
+  I->profiling = on != 0;
+  return COX_OK;
+}
+
+int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* apply_launches, int reset) {
+  COX_ENTRY();
+  if (!I) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  int st = integrator_finish(I);
+  if (apply_ms) *apply_ms = I->apply_ms;
+  if (apply_launches) *apply_launches = I->apply_launches;
+  if (reset) {
+    I->apply_ms = 0.0;
+    I->apply_launches = 0;
+  }
+  return st;
+}
+
+}  // extern "C"

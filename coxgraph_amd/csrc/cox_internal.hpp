@@ -1,9 +1,44 @@
 // Private host-side definitions shared by the translation units of libcoxgraph_hip.so.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/coxgraph_hip.h"
 #include "cox_device.hpp"
 
 using cox::u32;
 using cox::u64;
+
+#define COX_HIP(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) {                            \
+      fprintf(stderr, "[coxgraph_hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return (e_ == hipErrorOutOfMemory) ? COX_ERR_OUT_OF_MEMORY : COX_ERR_NO_DEVICE; \
+    }                                                  \
+  } while (0)
+
+// device error bits (layer->d_err / integrator counters.err)
+enum : u32 { kErrPool = 1u, kErrRange = 2u, kErrTable = 4u, kErrRecords = 8u };
+
+static inline int err_bits_to_status(u32 bits) {
+  if (bits & (kErrPool | kErrTable)) return COX_ERR_POOL_EXHAUSTED;
+  if (bits & kErrRange) return COX_ERR_INDEX_RANGE;
+  if (bits & kErrRecords) return COX_ERR_INTERNAL;
+  return COX_OK;
+}
+
+static inline u32 next_pow2(u64 v) {
+  u32 p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+static inline int ceil_log2(u64 v) {
+  int b = 0;
+  while ((1ull << b) < v) ++b;
+  return b;
+}
+
 
 struct cox_layer {
   int device = 0;
@@ -24,8 +59,6 @@ struct cox_layer {
 // hipGetLastError() is a per-thread sticky slot shared with every other HIP user in the process
 // (PyTorch probes peers / devices during its lazy init and may leave a benign error behind).  Every
 // entry point clears it first so that the check after our own launches only sees our own errors.
-#include <cstdio>
-#include <cstdlib>
 static inline void cox_clear_stale_hip_error(const char* where) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -1,0 +1,317 @@
+// MI355X (gfx950) TSDF layer storage behind include/coxgraph_hip.h (the integrator is in cox_integrator.hip).
+//
+// Replaces the work of voxblox's TsdfIntegratorBase::integratePointCloud as coxgraph calls it
+// (coxgraph/include/coxgraph/map_comm/tsdf_recover.h:75) and of Layer<TsdfVoxel> maintenance
+// (tsdf_recover.h:62,92,95; utils/msg_converter.h:49,107).  Design: DESIGN.md.
+//
+// Pipeline of one frame (all on the integrator's stream):
+//   rays      simple: one ray per valid point, canonical order = voxblox "mixed" sequence number
+//             merged: points bundled by terminal voxel (frame hash + stable radix sort), one ray per
+//                     bundle, canonical order = (clearing?, first visit)
+//   lengths   every ray knows its step count in O(1) (L1 index distance) -> exclusive scan -> each ray
+//             owns a contiguous slice of the record array
+//   touch     rays walk their voxels, insert block keys in the layer hash (bump-allocating pool
+//             blocks) and give every block touched this frame a dense ordinal
+//   emit      rays walk again and write (ordinal<<12 | linear voxel, ray id) records, ray-major
+//   sort      stable radix sort by voxel id -> per voxel, records are in canonical ray order
+//   apply     per voxel: the running weighted-mean/clamp update in exactly that order
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/coxgraph_hip.h"
+#include "cox_device.hpp"
+#include "cox_internal.hpp"
+
+using namespace cox;
+
+// =================================================================================================
+// Layer
+// =================================================================================================
+
+// pool blocks are zero (= TsdfVoxel{0,0,Color()}) whenever they are free, so allocation is a bump
+static int layer_reset_storage(cox_layer* L, u64 used_blocks, hipStream_t s) {
+  COX_HIP(hipMemsetAsync(L->ht_keys, 0xFF, sizeof(u64) * L->ht_cap, s));
+  COX_HIP(hipMemsetAsync(L->ht_vals, 0xFF, sizeof(u32) * L->ht_cap, s));
+  COX_HIP(hipMemsetAsync(L->ht_stamp, 0, sizeof(u32) * L->ht_cap, s));
+  COX_HIP(hipMemsetAsync(L->ht_ord, 0, sizeof(u32) * L->ht_cap, s));
+  if (used_blocks) COX_HIP(hipMemsetAsync(L->voxels, 0, used_blocks * kVoxelsPerBlock * kWordsPerVoxel * sizeof(u32), s));
+  COX_HIP(hipMemsetAsync(L->d_nblocks, 0, sizeof(u32), s));
+  COX_HIP(hipMemsetAsync(L->d_err, 0, sizeof(u32), s));
+  L->frame_id = 0;
+  return COX_OK;
+}
+
+static int layer_read_counters(const cox_layer* L, u32* nblocks, u32* err) {
+  COX_HIP(hipSetDevice(L->device));
+  COX_HIP(hipDeviceSynchronize());
+  u32 nb = 0, e = 0;
+  COX_HIP(hipMemcpy(&nb, L->d_nblocks, sizeof(u32), hipMemcpyDeviceToHost));
+  COX_HIP(hipMemcpy(&e, L->d_err, sizeof(u32), hipMemcpyDeviceToHost));
+  if (nb > L->capacity) nb = static_cast<u32>(L->capacity);
+  *nblocks = nb;
+  *err = e;
+  return COX_OK;
+}
+
+extern "C" {
+
+const char* cox_status_string(int s) {
+  switch (s) {
+    case COX_OK: return "COX_OK";
+    case COX_ERR_INVALID_ARG: return "COX_ERR_INVALID_ARG";
+    case COX_ERR_NO_DEVICE: return "COX_ERR_NO_DEVICE";
+    case COX_ERR_OUT_OF_MEMORY: return "COX_ERR_OUT_OF_MEMORY";
+    case COX_ERR_POOL_EXHAUSTED: return "COX_ERR_POOL_EXHAUSTED";
+    case COX_ERR_INDEX_RANGE: return "COX_ERR_INDEX_RANGE";
+    case COX_ERR_UNSUPPORTED: return "COX_ERR_UNSUPPORTED";
+    case COX_ERR_BUFFER_TOO_SMALL: return "COX_ERR_BUFFER_TOO_SMALL";
+    case COX_ERR_INTERNAL: return "COX_ERR_INTERNAL";
+  }
+  return "COX_ERR_?";
+}
+
+int cox_device_count(void) {
+  COX_ENTRY();
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void cox_tsdf_config_default(cox_tsdf_config* c) {
+  // voxblox TsdfIntegratorBase::Config defaults
+  c->default_truncation_distance = 0.1f;
+  c->max_weight = 10000.0f;
+  c->voxel_carving_enabled = 1;
+  c->min_ray_length_m = 0.1f;
+  c->max_ray_length_m = 5.0f;
+  c->use_const_weight = 0;
+  c->allow_clear = 1;
+  c->use_weight_dropoff = 1;
+  c->use_sparsity_compensation_factor = 0;
+  c->sparsity_compensation_factor = 1.0f;
+  c->integrator_threads = 1;
+  c->integration_order_mode = 0;
+  c->enable_anti_grazing = 0;
+  c->start_voxel_subsampling_factor = 2.0f;
+  c->max_consecutive_ray_collisions = 2;
+  c->clear_checks_every_n_frames = 1;
+  c->max_integration_time_s = 3.4e38f;
+  c->merged_bundle_order = 0;
+  c->fast_exact_sets = 0;
+}
+
+int cox_layer_create(float voxel_size, int voxels_per_side, int device, uint64_t capacity_blocks, cox_layer_t** out) {
+  COX_ENTRY();
+  if (!out || !(voxel_size > 0.0f) || voxels_per_side != kVps) return COX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return COX_ERR_NO_DEVICE;
+  COX_HIP(hipSetDevice(device));
+  cox_layer* L = new (std::nothrow) cox_layer();
+  if (!L) return COX_ERR_OUT_OF_MEMORY;
+  L->device = device;
+  L->voxel_size = voxel_size;
+  L->voxel_size_inv = static_cast<float>(1.0 / voxel_size);
+  L->block_size = voxel_size * static_cast<float>(kVps);
+  L->block_size_inv = static_cast<float>(1.0 / L->block_size);
+  L->capacity = capacity_blocks ? capacity_blocks : 16384;  // 16384 * 48 KiB = 768 MiB default
+  if (L->capacity > (1ull << 26)) {
+    delete L;
+    return COX_ERR_INVALID_ARG;
+  }
+  L->ht_cap = next_pow2(2 * L->capacity);
+  if (L->ht_cap < 1024) L->ht_cap = 1024;
+  const size_t vox_bytes = L->capacity * kVoxelsPerBlock * kWordsPerVoxel * sizeof(u32);
+  int st = COX_OK;
+  auto alloc = [&](void** p, size_t bytes) {
+    if (st != COX_OK) return;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) st = (e == hipErrorOutOfMemory) ? COX_ERR_OUT_OF_MEMORY : COX_ERR_NO_DEVICE;
+  };
+  alloc(reinterpret_cast<void**>(&L->voxels), vox_bytes);
+  alloc(reinterpret_cast<void**>(&L->ht_keys), sizeof(u64) * L->ht_cap);
+  alloc(reinterpret_cast<void**>(&L->ht_vals), sizeof(u32) * L->ht_cap);
+  alloc(reinterpret_cast<void**>(&L->ht_stamp), sizeof(u32) * L->ht_cap);
+  alloc(reinterpret_cast<void**>(&L->ht_ord), sizeof(u32) * L->ht_cap);
+  alloc(reinterpret_cast<void**>(&L->block_keys), sizeof(u64) * L->capacity);
+  alloc(reinterpret_cast<void**>(&L->d_nblocks), sizeof(u32));
+  alloc(reinterpret_cast<void**>(&L->d_err), sizeof(u32));
+  if (st == COX_OK) st = layer_reset_storage(L, L->capacity, nullptr);
+  if (st == COX_OK && hipDeviceSynchronize() != hipSuccess) st = COX_ERR_NO_DEVICE;
+  if (st != COX_OK) {
+    cox_layer_destroy(L);
+    return st;
+  }
+  *out = L;
+  return COX_OK;
+}
+
+void cox_layer_destroy(cox_layer_t* L) {
+  if (!L) return;
+  (void)hipSetDevice(L->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(L->voxels);
+  (void)hipFree(L->ht_keys);
+  (void)hipFree(L->ht_vals);
+  (void)hipFree(L->ht_stamp);
+  (void)hipFree(L->ht_ord);
+  (void)hipFree(L->block_keys);
+  (void)hipFree(L->d_nblocks);
+  (void)hipFree(L->d_err);
+  delete L;
+}
+
+int cox_layer_clear(cox_layer_t* L) {
+  COX_ENTRY();
+  if (!L) return COX_ERR_INVALID_ARG;
+  u32 nb, err;
+  int st = layer_read_counters(L, &nb, &err);
+  if (st != COX_OK) return st;
+  st = layer_reset_storage(L, nb, nullptr);
+  if (st != COX_OK) return st;
+  COX_HIP(hipDeviceSynchronize());
+  return COX_OK;
+}
+
+int cox_layer_stats(cox_layer_t* L, uint64_t* n_blocks, uint64_t* memory_bytes) {
+  COX_ENTRY();
+  if (!L) return COX_ERR_INVALID_ARG;
+  u32 nb, err;
+  int st = layer_read_counters(L, &nb, &err);
+  if (st != COX_OK) return st;
+  if (n_blocks) *n_blocks = nb;
+  if (memory_bytes) *memory_bytes = static_cast<uint64_t>(nb) * kVoxelsPerBlock * kWordsPerVoxel * sizeof(u32);
+  return err_bits_to_status(err);
+}
+
+int cox_layer_download(cox_layer_t* L, int32_t* block_idx_xyz, uint32_t* voxels_3u32, uint64_t cap_blocks, uint64_t* n_blocks) {
+  COX_ENTRY();
+  if (!L) return COX_ERR_INVALID_ARG;
+  u32 nb, err;
+  int st = layer_read_counters(L, &nb, &err);
+  if (st != COX_OK) return st;
+  if (n_blocks) *n_blocks = nb;
+  if (cap_blocks == 0 && !block_idx_xyz && !voxels_3u32) return err_bits_to_status(err);
+  if (cap_blocks < nb) return COX_ERR_BUFFER_TOO_SMALL;
+  if (nb == 0) return err_bits_to_status(err);
+  if (!block_idx_xyz || !voxels_3u32) return COX_ERR_INVALID_ARG;
+  std::vector<u64> keys(nb);
+  COX_HIP(hipMemcpy(keys.data(), L->block_keys, sizeof(u64) * nb, hipMemcpyDeviceToHost));
+  // deterministic (z,y,x) block order: the packed key already orders that way
+  std::vector<u32> order(nb);
+  for (u32 i = 0; i < nb; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return keys[a] < keys[b]; });
+  const size_t block_words = static_cast<size_t>(kVoxelsPerBlock) * kWordsPerVoxel;
+  for (u32 i = 0; i < nb; ++i) {
+    int x, y, z;
+    unpack_key(keys[order[i]], &x, &y, &z);
+    block_idx_xyz[3 * i + 0] = x;
+    block_idx_xyz[3 * i + 1] = y;
+    block_idx_xyz[3 * i + 2] = z;
+    COX_HIP(hipMemcpy(voxels_3u32 + i * block_words, L->voxels + static_cast<size_t>(order[i]) * block_words, block_words * sizeof(u32),
+                      hipMemcpyDeviceToHost));
+  }
+  return err_bits_to_status(err);
+}
+
+}  // extern "C"
+
+// ---- upload (deserializeMsgToLayer) -------------------------------------------------------------
+__global__ void k_upload_insert(u64* ht_keys, u32* ht_vals, u32 ht_mask, u64* block_keys, u32* d_nblocks, u32 capacity, u32* d_err,
+                                const int32_t* __restrict__ idx, u32 n, u32* __restrict__ pool_of) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = idx[3 * i], y = idx[3 * i + 1], z = idx[3 * i + 2];
+  pool_of[i] = kInvalid;
+  if (x < -kIdxBias + 1 || x >= kIdxBias - 1 || y < -kIdxBias + 1 || y >= kIdxBias - 1 || z < -kIdxBias + 1 || z >= kIdxBias - 1) {
+    atomicOr(d_err, kErrRange);
+    return;
+  }
+  const u64 key = pack_key(x, y, z);
+  bool fresh;
+  const u32 slot = ht_insert(ht_keys, ht_mask, key, &fresh);
+  if (slot == kInvalid) {
+    atomicOr(d_err, kErrTable);
+    return;
+  }
+  if (fresh) {
+    const u32 pool = atomicAdd(d_nblocks, 1u);
+    if (pool >= capacity) {
+      atomicOr(d_err, kErrPool);
+      return;
+    }
+    ht_vals[slot] = pool;
+    block_keys[pool] = key;
+    pool_of[i] = pool | 0x80000000u;  // bit 31: fresh (a message never repeats a block)
+  } else {
+    pool_of[i] = ht_vals[slot];  // block existed before this launch
+  }
+}
+// one workgroup per uploaded block; action 0/2: overwrite, 1: mergeVoxelAIntoVoxelB
+__global__ void __launch_bounds__(256) k_upload_copy(u32* __restrict__ voxels, const u32* __restrict__ src, const u32* __restrict__ pool_of, int action) {
+  const u32 b = blockIdx.x;
+  const u32 p = pool_of[b];
+  if (p == kInvalid) return;
+  const u32 pool = p & 0x7FFFFFFFu;
+  u32* dst = voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
+  const u32* s = src + static_cast<size_t>(b) * kVoxelsPerBlock * kWordsPerVoxel;
+  if (action != 1) {
+    for (u32 i = threadIdx.x; i < kVoxelsPerBlock * kWordsPerVoxel; i += blockDim.x) dst[i] = s[i];
+    return;
+  }
+  for (u32 v = threadIdx.x; v < kVoxelsPerBlock; v += blockDim.x) {
+    const float ad = __uint_as_float(s[3 * v]), aw = __uint_as_float(s[3 * v + 1]);
+    const u32 ac = s[3 * v + 2];
+    const float bd = __uint_as_float(dst[3 * v]), bw = __uint_as_float(dst[3 * v + 1]);
+    const u32 bc = dst[3 * v + 2];
+    const float cw = aw + bw;
+    if (cw > 0.0f) {
+      dst[3 * v] = __float_as_uint((ad * aw + bd * bw) / cw);
+      dst[3 * v + 2] = blend_colors(ac, aw, bc, bw);
+      dst[3 * v + 1] = __float_as_uint(cw);
+    }
+  }
+}
+
+extern "C" int cox_layer_upload(cox_layer_t* L, const int32_t* block_idx_xyz, const uint32_t* voxels_3u32, uint64_t n_blocks, int action) {
+  COX_ENTRY();
+  if (!L || action < 0 || action > 2 || (n_blocks && (!block_idx_xyz || !voxels_3u32))) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(L->device));
+  if (action == 2) {
+    int st = cox_layer_clear(L);
+    if (st != COX_OK) return st;
+  }
+  if (n_blocks == 0) return COX_OK;
+  if (n_blocks > L->capacity) return COX_ERR_POOL_EXHAUSTED;
+  const size_t block_words = static_cast<size_t>(kVoxelsPerBlock) * kWordsPerVoxel;
+  int32_t* d_idx = nullptr;
+  u32 *d_src = nullptr, *d_pool = nullptr;
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), sizeof(int32_t) * 3 * n_blocks));
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pool), sizeof(u32) * n_blocks));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_src), sizeof(u32) * block_words * n_blocks);
+  if (e != hipSuccess) {
+    (void)hipFree(d_idx);
+    (void)hipFree(d_pool);
+    return COX_ERR_OUT_OF_MEMORY;
+  }
+  COX_HIP(hipMemcpy(d_idx, block_idx_xyz, sizeof(int32_t) * 3 * n_blocks, hipMemcpyHostToDevice));
+  COX_HIP(hipMemcpy(d_src, voxels_3u32, sizeof(u32) * block_words * n_blocks, hipMemcpyHostToDevice));
+  const u32 n = static_cast<u32>(n_blocks);
+  hipLaunchKernelGGL(k_upload_insert, dim3((n + 255) / 256), dim3(256), 0, nullptr, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->block_keys,
+                     L->d_nblocks, static_cast<u32>(L->capacity), L->d_err, d_idx, n, d_pool);
+  hipLaunchKernelGGL(k_upload_copy, dim3(n), dim3(256), 0, nullptr, L->voxels, d_src, d_pool, action);
+  COX_HIP(hipDeviceSynchronize());
+  (void)hipFree(d_idx);
+  (void)hipFree(d_src);
+  (void)hipFree(d_pool);
+  u32 nb, err;
+  int st = layer_read_counters(L, &nb, &err);
+  if (st != COX_OK) return st;
+  return err_bits_to_status(err);
+}
+

@@ -23,16 +23,6 @@
 
 using namespace cox;
 
-#define COX_HIP(call)                                  \
-  do {                                                 \
-    hipError_t e_ = (call);                            \
-    if (e_ != hipSuccess) {                            \
-      fprintf(stderr, "[coxgraph_hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
-      return (e_ == hipErrorOutOfMemory) ? COX_ERR_OUT_OF_MEMORY : COX_ERR_NO_DEVICE; \
-    }                                                  \
-  } while (0)
-
-
 struct ReadingView {
   const u32* voxels;
   const u64* ht_keys;

@@ -1,8 +1,8 @@
 // Device-wide exclusive scan and stable LSD radix sort of (u32 key, u32 value) pairs for gfx950.
 //
-// Element counts live in device memory (d_n) so that no host round trip is needed between the
-// kernel that produces a count and the kernels that consume it; the host passes an upper bound
-// (n_max) that only sizes the grid.
+// Element counts AND the number of key bits may live in device memory, so a frame never needs a
+// host round trip between the kernel that produces a count and the kernels that consume it.  The
+// host only passes a *hint* that sizes the grids; every kernel grid-strides, so any hint is correct.
 //
 // The sort is STABLE: equal keys keep their input order.  The engine relies on that to get the
 // canonical per-voxel update order without carrying the order in the key.
@@ -27,56 +27,63 @@ __device__ __forceinline__ u32 wave_inclusive_scan(u32 v) {
   }
   return v;
 }
-// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total via *total
-__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* total, u32* lds /*[4]*/) {
+// block-wide exclusive scan of one value per thread; NW = waves per block; returns exclusive prefix
+template <int NW>
+__device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* total, u32* lds /*[NW]*/) {
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
   const u32 inc = wave_inclusive_scan(v);
   __syncthreads();  // protect lds reuse across calls
   if (lane == 63) lds[wave] = inc;
   __syncthreads();
-  u32 base = 0;
+  u32 base = 0, tot = 0;
 #pragma unroll
-  for (u32 w = 0; w < 4; ++w) {
+  for (u32 w = 0; w < NW; ++w) {
     const u32 s = lds[w];
     if (w < wave) base += s;
+    tot += s;
   }
-  *total = lds[0] + lds[1] + lds[2] + lds[3];
+  *total = tot;
   return base + inc - v;
 }
 
-// n = *d_n if d_n != nullptr else n_max
+// n = *d_n if d_n != nullptr else n_max; grid-strides over tiles, so any grid size is correct
 __global__ void __launch_bounds__(kScanThreads) k_scan_blocks(const u32* __restrict__ in, u32* __restrict__ out, u32* __restrict__ block_sums,
                                                               const u32* __restrict__ d_n, u32 n_max) {
   __shared__ u32 lds[4];
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
-  const u32 base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  u32 v[kScanItems];
-  u32 sum = 0;
+  const u32 n_tiles = (n + kScanTile - 1) / kScanTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const u32 base = tile * kScanTile + threadIdx.x * kScanItems;
+    u32 v[kScanItems];
+    u32 sum = 0;
 #pragma unroll
-  for (int i = 0; i < kScanItems; ++i) {
-    v[i] = (base + i < n) ? in[base + i] : 0u;
-    sum += v[i];
-  }
-  u32 total;
-  u32 ex = block_exclusive_scan_256(sum, &total, lds);
-#pragma unroll
-  for (int i = 0; i < kScanItems; ++i) {
-    if (base + i < n) out[base + i] = ex;
-    ex += v[i];
-  }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-// single block: exclusive scan of block sums in place; writes the grand total to *d_total
-__global__ void __launch_bounds__(kScanThreads) k_scan_sums(u32* __restrict__ block_sums, u32 n_blocks, u32* __restrict__ d_total) {
-  __shared__ u32 lds[4];
-  u32 carry = 0;
-  for (u32 base = 0; base < n_blocks; base += kScanThreads) {
-    const u32 i = base + threadIdx.x;
-    const u32 v = (i < n_blocks) ? block_sums[i] : 0u;
+    for (int i = 0; i < kScanItems; ++i) {
+      v[i] = (base + i < n) ? in[base + i] : 0u;
+      sum += v[i];
+    }
     u32 total;
-    const u32 ex = block_exclusive_scan_256(v, &total, lds);
-    if (i < n_blocks) block_sums[i] = carry + ex;
+    u32 ex = block_exclusive_scan<4>(sum, &total, lds);
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      if (base + i < n) out[base + i] = ex;
+      ex += v[i];
+    }
+    if (threadIdx.x == 0) block_sums[tile] = total;
+  }
+}
+// single block: exclusive scan of the tile sums in place; writes the grand total to *d_total
+__global__ void __launch_bounds__(1024) k_scan_sums(u32* __restrict__ block_sums, const u32* __restrict__ d_n, u32 n_max, u32* __restrict__ d_total) {
+  __shared__ u32 lds[16];
+  const u32 n = d_n ? min(*d_n, n_max) : n_max;
+  const u32 n_tiles = (n + kScanTile - 1) / kScanTile;
+  u32 carry = 0;
+  for (u32 base = 0; base < n_tiles; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = (i < n_tiles) ? block_sums[i] : 0u;
+    u32 total;
+    const u32 ex = block_exclusive_scan<16>(v, &total, lds);
+    if (i < n_tiles) block_sums[i] = carry + ex;
     carry += total;
   }
   if (threadIdx.x == 0 && d_total) *d_total = carry;
@@ -84,56 +91,109 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_sums(u32* __restrict__ bl
 __global__ void __launch_bounds__(kScanThreads) k_scan_add(u32* __restrict__ out, const u32* __restrict__ block_sums, const u32* __restrict__ d_n,
                                                            u32 n_max) {
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
-  const u32 add = block_sums[blockIdx.x];
-  const u32 base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  const u32 n_tiles = (n + kScanTile - 1) / kScanTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const u32 add = block_sums[tile];
+    const u32 base = tile * kScanTile + threadIdx.x * kScanItems;
 #pragma unroll
-  for (int i = 0; i < kScanItems; ++i)
-    if (base + i < n) out[base + i] += add;
+    for (int i = 0; i < kScanItems; ++i)
+      if (base + i < n) out[base + i] += add;
+  }
 }
 
 struct ScanWorkspace {
   u32* block_sums = nullptr;  // capacity >= ceil(n_max / kScanTile)
 };
-static inline u32 scan_num_blocks(u32 n_max) { return (n_max + kScanTile - 1) / kScanTile; }
-// out may alias in.  d_total (optional) receives the sum of all n inputs.
-static inline void exclusive_scan_u32(const u32* in, u32* out, const u32* d_n, u32 n_max, u32* d_total, const ScanWorkspace& ws, hipStream_t s) {
-  const u32 nb = scan_num_blocks(n_max);
-  if (nb == 0) {
-    if (d_total) (void)hipMemsetAsync(d_total, 0, sizeof(u32), s);
-    return;
-  }
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(kScanThreads), 0, s, in, out, ws.block_sums, d_n, n_max);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, s, ws.block_sums, nb, d_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanThreads), 0, s, out, ws.block_sums, d_n, n_max);
+static inline u32 scan_num_blocks(u32 n) { return (n + kScanTile - 1) / kScanTile; }
+// out may alias in.  d_total (optional) receives the sum of the n inputs.  n = min(*d_n, n_max) when
+// d_n is given; n_hint only sizes the grid.
+static inline void exclusive_scan_u32(const u32* in, u32* out, const u32* d_n, u32 n_max, u32 n_hint, u32* d_total, const ScanWorkspace& ws,
+                                      hipStream_t s) {
+  const u32 nb = scan_num_blocks(n_hint ? n_hint : 1);
+  const u32 grid = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(grid), dim3(kScanThreads), 0, s, in, out, ws.block_sums, d_n, n_max);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, ws.block_sums, d_n, n_max, d_total);
+  hipLaunchKernelGGL(k_scan_add, dim3(grid), dim3(kScanThreads), 0, s, out, ws.block_sums, d_n, n_max);
 }
 
 // ------------------------------------------------------------------------------------------------
-// stable LSD radix sort, 8-bit digits
+// stable LSD radix sort, RB-bit digits (RB = 8 or 11)
 // ------------------------------------------------------------------------------------------------
 constexpr int kRsThreads = 256;
 constexpr int kRsWaves = 4;
 constexpr int kRsRounds = 16;
-constexpr int kRsWaveTile = 64 * kRsRounds;         // 1024 elements per wave
-constexpr int kRsTile = kRsWaveTile * kRsWaves;     // 4096 elements per block
-constexpr int kRsRadix = 256;
+constexpr int kRsWaveTile = 64 * kRsRounds;      // 1024 elements per wave
+constexpr int kRsTile = kRsWaveTile * kRsWaves;  // 4096 elements per tile
+constexpr int kRsMaxPasses = 4;
 
-__global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ keys, const u32* __restrict__ d_n, u32 n_max, int shift,
-                                                        u32* __restrict__ counts /*[256][nb]*/, u32 nb) {
-  __shared__ u32 h[kRsRadix];
+// device-side description of one sort
+struct SortInfo {
+  u32 nbits;   // key bits to sort on (passes whose shift >= nbits do nothing)
+  u32 parity;  // 0: result in buffer 0, 1: result in buffer 1 (written by the kernels)
+};
+
+template <int RB>
+__global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ k0, const u32* __restrict__ k1, const u32* __restrict__ d_n, u32 n_max,
+                                                        int pass, const SortInfo* __restrict__ info, int host_bits, u32* __restrict__ counts /*[2^RB][n_tiles_cap]*/,
+                                                        u32 tiles_cap, u32* __restrict__ totals /*[2^RB]*/) {
+  constexpr u32 kDigits = 1u << RB;
+  __shared__ u32 h[kDigits];
+  const int shift = pass * RB;
+  if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
+  const u32* keys = (pass & 1) ? k1 : k0;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const u32 start = blockIdx.x * kRsTile;
-  for (u32 i = start + threadIdx.x; i < start + kRsTile && i < n; i += kRsThreads) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
-  __syncthreads();
-  counts[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+  const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) h[d] = 0;
+    __syncthreads();
+    const u32 start = tile * kRsTile;
+    for (u32 i = start + threadIdx.x; i < start + kRsTile && i < n; i += kRsThreads) atomicAdd(&h[(keys[i] >> shift) & (kDigits - 1)], 1u);
+    __syncthreads();
+    for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) {
+      const u32 c = h[d];
+      counts[static_cast<size_t>(d) * tiles_cap + tile] = c;
+      if (c) atomicAdd(&totals[d], c);
+    }
+    __syncthreads();
+  }
 }
 
-// wave-wide "which lanes hold my digit" (8 ballots), restricted to lanes with valid == true
+// one block per digit: counts[d][0..n_tiles) -> exclusive prefix over tiles + sum of the totals of all lower digits
+template <int RB>
+__global__ void __launch_bounds__(kRsThreads) k_rs_offsets(const u32* __restrict__ d_n, u32 n_max, int pass, SortInfo* __restrict__ info, int host_bits,
+                                                           u32* __restrict__ counts, u32 tiles_cap, const u32* __restrict__ totals) {
+  constexpr u32 kDigits = 1u << RB;
+  __shared__ u32 lds[4];
+  const int shift = pass * RB;
+  if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
+  const u32 n = d_n ? min(*d_n, n_max) : n_max;
+  const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
+  for (u32 d = blockIdx.x; d < kDigits; d += gridDim.x) {
+    // base = sum of totals[0..d)
+    u32 part = 0;
+    for (u32 j = threadIdx.x; j < d; j += kRsThreads) part += totals[j];
+    u32 base;
+    (void)block_exclusive_scan<4>(part, &base, lds);
+    u32* row = counts + static_cast<size_t>(d) * tiles_cap;
+    u32 carry = base;
+    for (u32 t0 = 0; t0 < n_tiles; t0 += kRsThreads) {
+      const u32 t = t0 + threadIdx.x;
+      const u32 v = (t < n_tiles) ? row[t] : 0u;
+      u32 total;
+      const u32 ex = block_exclusive_scan<4>(v, &total, lds);
+      if (t < n_tiles) row[t] = carry + ex;
+      carry += total;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) info->parity = (pass + 1) & 1;  // this pass will run: its output buffer is current
+}
+
+// wave-wide "which lanes hold my digit" (RB ballots), restricted to lanes with valid == true
+template <int RB>
 __device__ __forceinline__ u64 match_digit(u32 digit, bool valid) {
   u64 peers = __ballot(valid);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < RB; ++b) {
     const bool bit = (digit >> b) & 1u;
     const u64 m = __ballot(bit);
     peers &= bit ? m : ~m;
@@ -141,80 +201,99 @@ __device__ __forceinline__ u64 match_digit(u32 digit, bool valid) {
   return peers;
 }
 
-__global__ void __launch_bounds__(kRsThreads) k_rs_scatter(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
-                                                           u32* __restrict__ vals_out, const u32* __restrict__ d_n, u32 n_max, int shift,
-                                                           const u32* __restrict__ offsets /*scanned [256][nb]*/, u32 nb) {
-  __shared__ u32 wave_cnt[kRsWaves][kRsRadix];
-  __shared__ u32 base[kRsWaves][kRsRadix];
+template <int RB>
+__global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0, u32* __restrict__ v0, u32* __restrict__ k1, u32* __restrict__ v1,
+                                                           const u32* __restrict__ d_n, u32 n_max, int pass, const SortInfo* __restrict__ info, int host_bits,
+                                                           const u32* __restrict__ offsets, u32 tiles_cap) {
+  constexpr u32 kDigits = 1u << RB;
+  __shared__ u32 base[kRsWaves][kDigits];  // first per-wave digit counts, then per-wave running output positions
+  const int shift = pass * RB;
+  if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
+  const u32* keys_in = (pass & 1) ? k1 : k0;
+  const u32* vals_in = (pass & 1) ? v1 : v0;
+  u32* keys_out = (pass & 1) ? k0 : k1;
+  u32* vals_out = (pass & 1) ? v0 : v1;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
+  const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
-  for (u32 w = 0; w < kRsWaves; ++w) wave_cnt[w][threadIdx.x] = 0;
-  __syncthreads();
-  const u32 wstart = blockIdx.x * kRsTile + wave * kRsWaveTile;
-  // pass 1: per-wave digit counts of this wave's contiguous sub-tile
-  for (int r = 0; r < kRsRounds; ++r) {
-    const u32 i = wstart + r * 64 + lane;
-    if (i < n) atomicAdd(&wave_cnt[wave][(keys_in[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  {
-    // thread t owns digit t: global base of (block, digit) + counts of the lower waves
-    u32 run = offsets[threadIdx.x * nb + blockIdx.x];
-    for (u32 w = 0; w < kRsWaves; ++w) {
-      base[w][threadIdx.x] = run;
-      run += wave_cnt[w][threadIdx.x];
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (u32 w = 0; w < kRsWaves; ++w)
+      for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) base[w][d] = 0;
+    __syncthreads();
+    const u32 wstart = tile * kRsTile + wave * kRsWaveTile;
+    // pass 1: per-wave digit counts of this wave's contiguous sub-tile
+    for (int r = 0; r < kRsRounds; ++r) {
+      const u32 i = wstart + r * 64 + lane;
+      if (i < n) atomicAdd(&base[wave][(keys_in[i] >> shift) & (kDigits - 1)], 1u);
     }
-  }
-  __syncthreads();
-  // pass 2: stable placement.  Order = (block, wave, round, lane) = input order.
-  volatile u32* my_base = base[wave];
-  for (int r = 0; r < kRsRounds; ++r) {
-    const u32 i = wstart + r * 64 + lane;
-    const bool valid = i < n;
-    u32 key = 0, val = 0;
-    if (valid) {
-      key = keys_in[i];
-      val = vals_in[i];
+    __syncthreads();
+    // counts -> output positions: global position of (tile, digit) + counts of the lower waves
+    for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) {
+      u32 run = offsets[static_cast<size_t>(d) * tiles_cap + tile];
+#pragma unroll
+      for (u32 w = 0; w < kRsWaves; ++w) {
+        const u32 c = base[w][d];
+        base[w][d] = run;
+        run += c;
+      }
     }
-    const u32 digit = (key >> shift) & 255u;
-    const u64 peers = match_digit(digit, valid);
-    if (valid) {
-      const u32 rank = __popcll(peers & ((1ull << lane) - 1ull));
-      const u32 pos = my_base[digit] + rank;
-      keys_out[pos] = key;
-      vals_out[pos] = val;
+    __syncthreads();
+    // pass 2: stable placement.  Order = (tile, wave, round, lane) = input order.
+    volatile u32* my_base = base[wave];
+    for (int r = 0; r < kRsRounds; ++r) {
+      const u32 i = wstart + r * 64 + lane;
+      const bool valid = i < n;
+      u32 key = 0, val = 0;
+      if (valid) {
+        key = keys_in[i];
+        val = vals_in[i];
+      }
+      const u32 digit = (key >> shift) & (kDigits - 1);
+      const u64 peers = match_digit<RB>(digit, valid);
+      const u64 lower = peers & ((1ull << lane) - 1ull);
+      if (valid) {
+        const u32 pos = my_base[digit] + static_cast<u32>(__popcll(lower));
+        keys_out[pos] = key;
+        vals_out[pos] = val;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (valid && lower == 0ull) my_base[digit] += static_cast<u32>(__popcll(peers));  // group leader
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) my_base[digit] += static_cast<u32>(__popcll(peers));  // group leader
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 
 struct SortWorkspace {
-  u32* counts = nullptr;  // capacity >= 256 * ceil(n_max / kRsTile)
-  ScanWorkspace scan;     // capacity >= scan_num_blocks(256 * ceil(n_max / kRsTile))
+  u32* counts = nullptr;   // [2^11][tiles_cap]
+  u32 tiles_cap = 0;       // >= ceil(capacity / kRsTile)
+  u32* totals = nullptr;   // [kRsMaxPasses][2^11], zeroed by the sort
+  SortInfo* info = nullptr;  // device
 };
-static inline u32 sort_num_blocks(u32 n_max) { return (n_max + kRsTile - 1) / kRsTile; }
+static inline u32 sort_num_tiles(u64 n) { return static_cast<u32>((n + kRsTile - 1) / kRsTile); }
 
-// Sorts by key bits [0, nbits).  Buffers ping-pong: input in (k0, v0); returns 0 if the result is
-// in (k0, v0), 1 if it is in (k1, v1).
-static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32* d_n, u32 n_max, int nbits, const SortWorkspace& ws,
-                                   hipStream_t s) {
-  const u32 nb = sort_num_blocks(n_max);
-  if (nb == 0 || nbits <= 0) return 0;
-  int cur = 0;
-  for (int shift = 0; shift < nbits; shift += 8) {
-    u32* ki = cur ? k1 : k0;
-    u32* vi = cur ? v1 : v0;
-    u32* ko = cur ? k0 : k1;
-    u32* vo = cur ? v0 : v1;
-    hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(kRsThreads), 0, s, ki, d_n, n_max, shift, ws.counts, nb);
-    exclusive_scan_u32(ws.counts, ws.counts, nullptr, 256u * nb, nullptr, ws.scan, s);
-    hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, d_n, n_max, shift, ws.counts, nb);
-    cur ^= 1;
+// Sorts (k0,v0) by key bits [0, nbits).  Buffers ping-pong; the buffer that holds the result is
+// returned when nbits is known on the host (bits_on_device == false).  Otherwise nbits is read from
+// ws.info->nbits (written by an earlier kernel of the frame), max_passes passes are enqueued (surplus
+// ones exit at once), the result buffer is reported in ws.info->parity (device) and -1 is returned.
+template <int RB>
+static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32* d_n, u32 n_max, u32 n_hint, int host_bits, bool bits_on_device,
+                                   int max_passes, const SortWorkspace& ws, hipStream_t s) {
+  const u32 nt = sort_num_tiles(n_hint ? n_hint : 1);
+  const u32 grid = nt < 1 ? 1 : (nt > 8192 ? 8192 : nt);
+  int passes = max_passes;
+  if (!bits_on_device) passes = (host_bits + RB - 1) / RB;
+  if (passes > kRsMaxPasses) passes = kRsMaxPasses;
+  const int hb = bits_on_device ? -1 : host_bits;
+  (void)hipMemsetAsync(ws.totals, 0, sizeof(u32) * kRsMaxPasses * (1u << 11), s);
+  for (int p = 0; p < passes; ++p) {
+    u32* totals = ws.totals + static_cast<size_t>(p) * (1u << 11);
+    hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_offsets<RB>, dim3(1u << RB), dim3(kRsThreads), 0, s, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap);
   }
-  return cur;
+  return bits_on_device ? -1 : (passes & 1);
 }
 
 }  // namespace cox
