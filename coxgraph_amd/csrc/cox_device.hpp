@@ -61,6 +61,13 @@ __device__ __forceinline__ u32 mixed_index(u32 seq, u32 n) {
   return (seq % groups) * 1024u + seq / groups;
 }
 
+// inverse of mixed_index: the sequence number at which point idx is visited
+__device__ __forceinline__ u32 mixed_sequence(u32 idx, u32 n) {
+  const u32 groups = n >> 10;
+  if ((groups << 10) <= idx) return idx;
+  return (idx & 1023u) * groups + (idx >> 10);
+}
+
 __device__ __forceinline__ int grid_index(float scaled) { return static_cast<int>(floorf(scaled + kEps)); }
 __device__ __forceinline__ bool index_in_range(float scaled) {
   // conservative: floor(scaled + eps) must land in [-2^20, 2^20)
@@ -140,7 +147,8 @@ struct Dda {
   int sgn[3];
   float t_next[3];
   float t_step[3];
-  u32 nsteps;  // indices this ray emits (ray_length_in_steps + 1), 0 for a NaN / out-of-range ray
+  u32 n_axis[3];  // |end index - start index| per axis
+  u32 nsteps;     // indices this ray emits (ray_length_in_steps + 1), 0 for a NaN / out-of-range ray
   bool range_error;
 };
 
@@ -174,6 +182,7 @@ __device__ __forceinline__ void dda_setup(Dda& d, const FrameParams& P, F3 point
   }
   d.nsteps = 0;
   d.range_error = false;
+  d.n_axis[0] = d.n_axis[1] = d.n_axis[2] = 0;
   if (isnan(s.x) || isnan(s.y) || isnan(s.z) || isnan(e.x) || isnan(e.y) || isnan(e.z)) return;
   if (!(index_in_range(s.x) && index_in_range(s.y) && index_in_range(s.z) && index_in_range(e.x) && index_in_range(e.y) && index_in_range(e.z))) {
     d.range_error = true;
@@ -187,7 +196,8 @@ __device__ __forceinline__ void dda_setup(Dda& d, const FrameParams& P, F3 point
     d.c[k] = grid_index(st[k]);
     const int ei = grid_index(en[k]);
     const int diff = ei - d.c[k];
-    len += static_cast<u32>(diff < 0 ? -diff : diff);
+    d.n_axis[k] = static_cast<u32>(diff < 0 ? -diff : diff);
+    len += d.n_axis[k];
     const float ray = en[k] - st[k];
     const int sg = signum(ray);
     d.sgn[k] = sg;

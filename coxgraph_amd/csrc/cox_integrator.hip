@@ -101,6 +101,9 @@ __device__ __forceinline__ float voxel_weight(const FrameParams& P, F3 p) {
   if (dz > kEps) return 1.0f / (dz * dz);
   return 0.0f;
 }
+// wave-uniform values must be made visibly scalar (SGPR): hipcc's divergence analysis treats threadIdx.x >> 6 as
+// per-lane, which turns every wave-cooperative loop below into a predicated / waterfall loop
+__device__ __forceinline__ u32 uniform_u32(u32 v) { return static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 __device__ __forceinline__ float readlane_f32(float v, u32 lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
 // ---- simple: one ray per point, ray id = mixed-order sequence number --------------------------
@@ -137,38 +140,60 @@ __global__ void __launch_bounds__(256) k_rays_simple(FrameParams P, const float*
 }
 
 // ---- merged: bundle points by terminal voxel ---------------------------------------------------
-// thread = sequence number; inserts the terminal-voxel key in the per-frame hash and records the
-// first (smallest) sequence number of each bundle
+// thread = point (so neighbouring lanes are neighbouring pixels and mostly share a terminal voxel): the lanes of a
+// wave that hold the same key elect one leader, which inserts the key in the per-frame hash once and records the
+// smallest sequence number of the group as a candidate for the bundle's first visit.  pslot is indexed by the
+// point's "mixed" sequence number, the order the bundling sort must start from.
 __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const float* __restrict__ xyz, u64* __restrict__ fh_keys, u32* __restrict__ fh_first,
                                                        u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
-  const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seq >= P.n_points) return;
-  const u32 idx = mixed_index(seq, P.n_points);
-  const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
-  bool clearing = false;
-  bool valid = point_valid(P, p, &clearing);
-  u32 slot = kInvalid;
-  if (valid) {
-    const F3 pg = transform_point(P, p);
-    const float sx = pg.x * P.voxel_size_inv, sy = pg.y * P.voxel_size_inv, sz = pg.z * P.voxel_size_inv;
-    if (!(index_in_range(sx) && index_in_range(sy) && index_in_range(sz))) {  // also catches NaN
-      atomicOr(&cnt->err, kErrRange);
-      valid = false;
-    } else {
-      const u64 key = pack_key(grid_index(sx), grid_index(sy), grid_index(sz)) | (clearing ? (1ull << 63) : 0ull);
-      bool fresh;
-      slot = ht_insert(fh_keys, fh_mask, key, &fresh);
-      if (slot == kInvalid) {
-        atomicOr(&cnt->err, kErrTable);
+  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 lane = lane_id();
+  bool valid = false;
+  u64 key = 0;
+  u32 seq = kInvalid;
+  if (idx < P.n_points) {
+    seq = mixed_sequence(idx, P.n_points);
+    const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    bool clearing = false;
+    valid = point_valid(P, p, &clearing);
+    if (valid) {
+      const F3 pg = transform_point(P, p);
+      const float sx = pg.x * P.voxel_size_inv, sy = pg.y * P.voxel_size_inv, sz = pg.z * P.voxel_size_inv;
+      if (!(index_in_range(sx) && index_in_range(sy) && index_in_range(sz))) {  // also catches NaN
+        atomicOr(&cnt->err, kErrRange);
         valid = false;
-      } else if (__hip_atomic_load(&fh_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > seq) {
-        atomicMin(&fh_first[slot], seq);  // a stale (larger) value read above only costs this atomic
+      } else {
+        key = pack_key(grid_index(sx), grid_index(sy), grid_index(sz)) | (clearing ? (1ull << 63) : 0ull);
       }
     }
   }
-  pslot[seq] = valid ? slot : kInvalid;
-  const u64 m = __ballot(valid);
-  if (lane_id() == 0 && m) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
+  u32 slot = kInvalid;
+  u64 todo = __ballot(valid);
+  while (todo) {
+    const u32 leader = static_cast<u32>(__ffsll(static_cast<long long>(todo))) - 1u;
+    const u64 k = (static_cast<u64>(static_cast<u32>(__builtin_amdgcn_readlane(static_cast<u32>(key >> 32), leader))) << 32) |
+                  static_cast<u64>(static_cast<u32>(__builtin_amdgcn_readlane(static_cast<u32>(key), leader)));
+    const bool mine = valid && key == k;
+    const u64 peers = __ballot(mine);
+    u32 mn = mine ? seq : kInvalid;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = min(mn, static_cast<u32>(__shfl_xor(static_cast<int>(mn), off, 64)));
+    u32 sl = kInvalid;
+    if (lane == leader) {
+      bool fresh;
+      sl = ht_insert(fh_keys, fh_mask, k, &fresh);
+      if (sl == kInvalid)
+        atomicOr(&cnt->err, kErrTable);
+      else if (__hip_atomic_load(&fh_first[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > mn)
+        atomicMin(&fh_first[sl], mn);  // a stale (larger) value read above only costs this atomic
+    }
+    sl = static_cast<u32>(__builtin_amdgcn_readlane(sl, leader));
+    if (mine) slot = sl;
+    todo &= ~peers;
+  }
+  if (idx < P.n_points) pslot[seq] = slot;  // kInvalid for points that are not integrated
+  const u64 m = __ballot(valid && slot != kInvalid);
+  if (lane == 0 && m) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
 }
 // sort key of a point = (clearing ? np2 : 0) + first sequence number of its bundle; value = seq
 __global__ void __launch_bounds__(256) k_bundle_keys(u32 n, u32 np2, const u64* __restrict__ fh_keys, const u32* __restrict__ fh_first,
@@ -199,30 +224,43 @@ __global__ void __launch_bounds__(256) k_bundle_starts(u32 n, const u32* __restr
 // wave = bundle: the sequential weighted mean of its points in visiting order, bit-exact with the
 // single-threaded reference loop
 //     merged = (merged * W + p * w) / (W + w);  colour = blend(colour, W, c, w);  W += w
-// 64 points at a time are gathered in parallel and everything that does not depend on the running
-// mean (W prefix, denominators, colour blend factors) is computed lane-parallel; the dependent chain
-// itself is split over lanes by role: lanes 0-2 carry x, y, z (one IEEE divide per step), lanes 3-6 the
-// four colour channels (multiply-add-round per step).
+// Written as one recurrence  val <- post((val * M_k + A_k) / D_k)  per component:
+//     x, y, z:     M = W_k,           A = p * w,             D = W_k + w,  post = identity
+//     r, g, b, a:  M = W_k / (W_k+w), A = c * (w / (W_k+w)), D = 1,        post = round   (x / 1 is exact)
+// 64 points at a time are gathered in parallel and their (M, A, D) operands -- everything that does not depend
+// on the running value -- are computed lane-parallel into an LDS table [point][component]; lanes 0-6 then each
+// carry one component through the dependent chain with one LDS read per step and no branches.  Skipped points
+// (w < eps, or anything after the first point of a clearing bundle) are the identity step (M, A, D) = (1, 0, 1).
+typedef float MergeOp __attribute__((ext_vector_type(4)));  // (M, A, D, unused)
+// the table is written and read by the same wave: keep the compiler from moving LDS accesses across the hand-over
+__device__ __forceinline__ void wave_lds_handover() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_wave_barrier();
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
 __global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba,
                                                       const u32* __restrict__ skey, const u32* __restrict__ sval, const u32* __restrict__ bstart,
                                                       RayArrays R, Counters* cnt) {
-  const u32 n_bundles = cnt->n_rays;
-  const u32 n_valid = cnt->n_valid;
+  __shared__ MergeOp ops[4][64][8];
+  const u32 n_bundles = uniform_u32(cnt->n_rays);
+  const u32 n_valid = uniform_u32(cnt->n_valid);
   const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nthreads = gridDim.x * blockDim.x;
   const u32 lane = lane_id();
+  const u32 role = lane & 7u;  // lanes 0-6 carry a component; the others run along harmlessly on column 7
   const bool is_pos = lane < 3;
-  const u32 shift = (lane >= 3 && lane < 7) ? 8u * (lane - 3u) : 0u;
-  for (u32 m = tid >> 6; m < n_bundles; m += nthreads >> 6) {
-    const u32 begin = bstart[m];
-    const u32 end = (m + 1 < n_bundles) ? bstart[m + 1] : n_valid;
-    const bool clearing = skey[begin] >= np2;
+  MergeOp(*tbl)[8] = ops[threadIdx.x >> 6];
+  for (u32 m = uniform_u32(tid >> 6); m < n_bundles; m += nthreads >> 6) {
+    const u32 begin = uniform_u32(bstart[m]);
+    const u32 end = uniform_u32((m + 1 < n_bundles) ? bstart[m + 1] : n_valid);
+    const bool clearing = uniform_u32(skey[begin]) >= np2;
     float val = 0.0f;  // this lane's component of the running mean / colour channel
     float W = 0.0f;    // uniform
     u64 key = 0;
     bool done = false;
     for (u32 base = begin; base < end && !done; base += 64) {
       const u32 i = base + lane;
+      const u32 cnt_in = min(64u, end - base);
       float px = 0.0f, py = 0.0f, pz = 0.0f, w = 0.0f;
       u32 col = 0;
       if (i < end) {
@@ -237,41 +275,57 @@ __global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, co
         const F3 pg = transform_point(P, F3{readlane_f32(px, 0), readlane_f32(py, 0), readlane_f32(pz, 0)});
         key = pack_key(grid_index(pg.x * P.voxel_size_inv), grid_index(pg.y * P.voxel_size_inv), grid_index(pg.z * P.voxel_size_inv));
       }
-      const u32 cnt_in = min(64u, end - base);
-      // W before each point of the chunk (points with w < eps are skipped and leave W unchanged)
+      // which points take part
+      bool used = (lane < cnt_in) && !(w < kEps);
+      if (clearing) {  // only the first point of a clearing bundle is used
+        const u64 um = __ballot(used);
+        used = used && (lane == static_cast<u32>(__ffsll(static_cast<long long>(um))) - 1u);
+        if (um) done = true;
+      }
+      // W before each point of the chunk (skipped points leave W unchanged)
       float Wpre;
       const u64 in_mask = (cnt_in == 64) ? ~0ull : ((1ull << cnt_in) - 1ull);
-      if ((__ballot(w == 1.0f) & in_mask) == in_mask && W == truncf(W) && W < 8388608.0f) {
+      if (!clearing && (__ballot(w == 1.0f) & in_mask) == in_mask && W == truncf(W) && W < 8388608.0f) {
         Wpre = W + static_cast<float>(lane);  // integers: every partial sum is exact
       } else {
         float run = W;
         Wpre = W;
         for (u32 k = 0; k < cnt_in; ++k) {
           if (lane == k) Wpre = run;
+          const bool uk = (__ballot(used) >> k) & 1ull;
           const float wk = readlane_f32(w, k);
-          if (!(wk < kEps)) run += wk;
+          if (uk) run += wk;
         }
       }
       const float den = Wpre + w;
       const float fa = Wpre / den, fb = w / den;  // colour blend factors of this point
-      for (u32 k = 0; k < cnt_in; ++k) {
-        const float w1 = readlane_f32(w, k);
-        if (w1 < kEps) continue;
-        const float Wk = readlane_f32(Wpre, k);
-        const u32 c1 = static_cast<u32>(__builtin_amdgcn_readlane(col, k));
-        const float x1 = readlane_f32(px, k), y1 = readlane_f32(py, k), z1 = readlane_f32(pz, k);
-        const float in = (lane == 0) ? x1 : (lane == 1) ? y1 : (lane == 2) ? z1 : static_cast<float>(static_cast<int>((c1 >> shift) & 255u));
-        if (is_pos) {
-          val = (val * Wk + in * w1) / readlane_f32(den, k);
+      const float Wnext = used ? den : Wpre;
+      // operand table of this chunk
+      if (lane < cnt_in) {
+        MergeOp* row = tbl[lane];
+        if (used) {
+          row[0] = MergeOp{Wpre, px * w, den, 0.0f};
+          row[1] = MergeOp{Wpre, py * w, den, 0.0f};
+          row[2] = MergeOp{Wpre, pz * w, den, 0.0f};
+#pragma unroll
+          for (u32 c = 0; c < 4; ++c) row[3 + c] = MergeOp{fa, static_cast<float>(static_cast<int>((col >> (8u * c)) & 255u)) * fb, 1.0f, 0.0f};
+          row[7] = MergeOp{1.0f, 0.0f, 1.0f, 0.0f};
         } else {
-          val = roundf(val * readlane_f32(fa, k) + in * readlane_f32(fb, k));
-        }
-        W = Wk + w1;
-        if (clearing) {  // only the first point of a clearing bundle is used
-          done = true;
-          break;
+#pragma unroll
+          for (u32 c = 0; c < 8; ++c) row[c] = MergeOp{1.0f, 0.0f, 1.0f, 0.0f};
         }
       }
+      wave_lds_handover();
+      // the dependent chain
+      MergeOp nxt = tbl[0][role];
+      for (u32 k = 0; k < cnt_in; ++k) {
+        const MergeOp op = nxt;
+        nxt = tbl[(k + 1) & 63u][role];  // prefetch: the operands do not depend on the chain
+        const float q = (val * op.x + op.y) / op.z;
+        val = is_pos ? q : roundf(q);
+      }
+      wave_lds_handover();
+      W = readlane_f32(Wnext, cnt_in - 1);
     }
     const float mx = readlane_f32(val, 0), my = readlane_f32(val, 1), mz = readlane_f32(val, 2);
     u32 mcolor = 0;
@@ -394,6 +448,268 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams P, RayArrays R, LayerV
   }
 }
 
+// ---- wave-per-ray traversal (few, long rays: the merged integrator's bundles) -----------------------------
+// A DDA is a dependent chain, so lane-per-ray leaves the chip empty when a frame has only a few thousand rays.
+// Here one wave walks one ray in parallel and reproduces the sequential argmin walk bit for bit:
+//   - per axis, the plane-crossing times are the reference's own repeated float additions
+//     T_k(j+1) = fl(T_k(j) + t_step_k) (three short chains, one lane each, into LDS);
+//   - "pick the smallest t, first axis wins ties" is a 3-way stable merge of those sorted sequences, so the
+//     position of crossing (k, j) in the walk is j + #{crossings of the other axes that precede it}, found by
+//     binary search; the same counts are the voxel's offset from the start voxel;
+//   - rays the argument does not cover (a zero ray component gives -inf / NaN times, very long rays, or a walk
+//     that would need more crossings of one axis than were generated) fall back to the sequential walk on lane 0.
+constexpr u32 kAxisCap = 512;
+constexpr u32 kRayFallback = 4u;  // ray flag
+
+__device__ __forceinline__ u32 pack_path(u32 jx, u32 jy, u32 jz) { return jx | (jy << 10) | (jz << 20); }
+// entries of the sorted array a[0, n) that precede t: a[i] < t, or a[i] <= t when inclusive
+__device__ __forceinline__ u32 count_before(const volatile float* a, u32 n, float t, bool inclusive) {
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    const float v = a[mid];
+    const bool before = inclusive ? (v <= t) : (v < t);
+    if (before)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+// sequential argmin step that also reports the chosen axis
+__device__ __forceinline__ int dda_step_axis(Dda& d) {
+  int k = 0;
+  float best = d.t_next[0];
+  if (d.t_next[1] < best) {
+    best = d.t_next[1];
+    k = 1;
+  }
+  if (d.t_next[2] < best) k = 2;
+  d.c[0] += (k == 0) ? d.sgn[0] : 0;
+  d.c[1] += (k == 1) ? d.sgn[1] : 0;
+  d.c[2] += (k == 2) ? d.sgn[2] : 0;
+  d.t_next[0] = (k == 0) ? d.t_next[0] + d.t_step[0] : d.t_next[0];
+  d.t_next[1] = (k == 1) ? d.t_next[1] + d.t_step[1] : d.t_next[1];
+  d.t_next[2] = (k == 2) ? d.t_next[2] + d.t_step[2] : d.t_next[2];
+  return k;
+}
+// Fills path[0, ns) (LDS, this wave's) with the packed per-axis crossing counts of every step.  Returns false
+// when the ray needs the sequential fallback (nothing usable was written).
+__device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, volatile float* tl /*[3][kAxisCap]*/, volatile u32* path, u32 lane) {
+  if (d0.sgn[0] == 0 || d0.sgn[1] == 0 || d0.sgn[2] == 0) return false;
+  const u32 g0 = d0.n_axis[0] + 2, g1 = d0.n_axis[1] + 2, g2 = d0.n_axis[2] + 2;
+  if (g0 > kAxisCap || g1 > kAxisCap || g2 > kAxisCap || ns > 3 * kAxisCap) return false;
+  const u32 L = ns - 1;
+  if (lane < 3) {
+    float T = (lane == 0) ? d0.t_next[0] : (lane == 1) ? d0.t_next[1] : d0.t_next[2];
+    const float st = (lane == 0) ? d0.t_step[0] : (lane == 1) ? d0.t_step[1] : d0.t_step[2];
+    const u32 g = (lane == 0) ? g0 : (lane == 1) ? g1 : g2;
+    volatile float* row = tl + lane * kAxisCap;
+    for (u32 j = 0; j < g; ++j) {
+      row[j] = T;
+      T += st;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const u32 E = g0 + g1 + g2;
+  bool bad = false;
+  for (u32 eb = 0; eb < E; eb += 64) {
+    const u32 e = eb + lane;
+    if (e < E) {
+      const u32 k = (e < g0) ? 0u : (e < g0 + g1) ? 1u : 2u;
+      const u32 j = (k == 0) ? e : (k == 1) ? e - g0 : e - g0 - g1;
+      const float t = tl[k * kAxisCap + j];
+      if (isnan(t)) bad = true;
+      // crossings that precede (k, j): own axis j, lower axes on <=, higher axes on <
+      const u32 c0 = (k == 0) ? j : count_before(tl, g0, t, true);
+      const u32 c1 = (k == 1) ? j : count_before(tl + kAxisCap, g1, t, k > 1);
+      const u32 c2 = (k == 2) ? j : count_before(tl + 2 * kAxisCap, g2, t, false);
+      const u32 rank = c0 + c1 + c2;
+      if (rank < L) {
+        path[rank + 1] = pack_path(c0 + (k == 0 ? 1u : 0u), c1 + (k == 1 ? 1u : 0u), c2 + (k == 2 ? 1u : 0u));
+        const u32 g = (k == 0) ? g0 : (k == 1) ? g1 : g2;
+        if (j == g - 1) bad = true;  // the walk would go on to a crossing that was not generated
+      }
+    }
+  }
+  if (lane == 0) path[0] = 0;
+  __builtin_amdgcn_wave_barrier();
+  return __ballot(bad) == 0ull;
+}
+
+__device__ __forceinline__ void touch_block(const FrameParams& P, const LayerView& L, u64 bkey, u32* touched_slots, Counters* cnt, u32* layer_err) {
+  bool fresh;
+  const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
+  if (slot == kInvalid) {
+    atomicOr(layer_err, kErrTable);
+    return;
+  }
+  if (fresh) {
+    const u32 pool = atomicAdd(L.d_nblocks, 1u);
+    if (pool < L.capacity) {
+      L.ht_vals[slot] = pool;  // read by later kernels only
+      L.block_keys[pool] = bkey;
+      atomicAdd(&cnt->n_new_blocks, 1u);
+    } else {
+      atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped
+    }
+  }
+  if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
+      atomicExch(&L.ht_stamp[slot], P.frame_id) != P.frame_id) {
+    const u32 ord = atomicAdd(&cnt->n_touched, 1u);
+    touched_slots[ord] = slot;
+    L.ht_ord[slot] = ord;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_touch_wave(FrameParams P, RayArrays R, LayerView L, u32* __restrict__ touched_slots, u32* __restrict__ path_out,
+                                                    u32 rec_cap, Counters* cnt, u32* layer_err, const u64* __restrict__ fh_keys, u32 fh_mask) {
+  __shared__ float lds_t[4][3 * kAxisCap];
+  __shared__ u32 lds_path[4][3 * kAxisCap];
+  const u32 n_slots = uniform_u32(cnt->n_ray_slots);
+  const bool overflow = uniform_u32(cnt->n_records) > rec_cap;
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x >> 6;
+  volatile float* tl = lds_t[wave];
+  volatile u32* path = lds_path[wave];
+  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_slots; r += waves_total) {
+    const u32 ns = uniform_u32(R.nsteps[r]);
+    if (ns == 0) continue;
+    const u32 flags = uniform_u32(R.flags[r]);
+    const bool clearing = (flags & 2u) != 0;
+    const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
+    const u64 own_key = P.anti_grazing ? R.key[r] : 0ull;
+    Dda d;
+    dda_setup(d, P, pg, clearing);
+    const bool par = wave_ray_path(d, ns, tl, path, lane);
+    if (lane == 0) R.flags[r] = par ? (flags & ~kRayFallback) : (flags | kRayFallback);
+    if (par) {
+      const u32 off = uniform_u32(R.rec_off[r]);
+      u64 carry = kEmptyKey;
+      for (u32 base = 0; base < ns; base += 64) {
+        const u32 s = base + lane;
+        const bool act = s < ns;
+        u64 bkey = kEmptyKey;
+        bool skip = false;
+        if (act) {
+          const u32 p = path[s];
+          if (!overflow) path_out[off + s] = p;  // emit reads the walk instead of redoing it
+          const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];
+          const int y = d.c[1] + static_cast<int>((p >> 10) & 1023u) * d.sgn[1];
+          const int z = d.c[2] + static_cast<int>(p >> 20) * d.sgn[2];
+          skip = grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z);
+          bkey = pack_key(x >> 4, y >> 4, z >> 4);
+        }
+        u64 prev = __shfl_up(bkey, 1, 64);
+        if (lane == 0) prev = carry;
+        if (act && !skip && bkey != prev) touch_block(P, L, bkey, touched_slots, cnt, layer_err);
+        carry = __shfl(bkey, 63, 64);
+      }
+    } else if (lane == 0) {
+      // sequential fallback
+      u64 last_bkey = kEmptyKey;
+      for (u32 s = 0; s < ns; ++s) {
+        const int x = d.c[0], y = d.c[1], z = d.c[2];
+        dda_step(d);
+        if (grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z)) continue;
+        const u64 bkey = pack_key(x >> 4, y >> 4, z >> 4);
+        if (bkey == last_bkey) continue;
+        last_bkey = bkey;
+        touch_block(P, L, bkey, touched_slots, cnt, layer_err);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_emit_wave(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ path_in, u32* __restrict__ rec_key,
+                                                   u32* __restrict__ rec_ray, u32 rec_cap, Counters* cnt, SortInfo* sort_info,
+                                                   const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const u32 n_slots = uniform_u32(cnt->n_ray_slots);
+  const bool overflow = uniform_u32(cnt->n_records) > rec_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
+    u32 bits = 12;
+    while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
+    sort_info->nbits = overflow ? 0u : bits;  // 0 bits: every sort pass exits at once
+    sort_info->parity = 0;
+    if (overflow) atomicOr(&cnt->err, kErrRecords);
+  }
+  if (overflow) return;  // frame dropped as a whole (reported at sync); never a partial update
+  const u32 lane = lane_id();
+  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_slots; r += waves_total) {
+    const u32 ns = uniform_u32(R.nsteps[r]);
+    if (ns == 0) continue;
+    const u32 flags = uniform_u32(R.flags[r]);
+    const bool clearing = (flags & 2u) != 0;
+    const u32 off = uniform_u32(R.rec_off[r]);
+    const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
+    const u64 own_key = P.anti_grazing ? R.key[r] : 0ull;
+    Dda d;
+    dda_setup(d, P, pg, clearing);
+    if (!(flags & kRayFallback)) {
+      u64 carry_key = kEmptyKey;
+      u32 carry_ord = kInvalid;
+      for (u32 base = 0; base < ns; base += 64) {
+        const u32 s = base + lane;
+        const bool act = s < ns;
+        u64 bkey = kEmptyKey;
+        bool skip = false;
+        u32 lin = 0;
+        if (act) {
+          const u32 p = path_in[off + s];
+          const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];
+          const int y = d.c[1] + static_cast<int>((p >> 10) & 1023u) * d.sgn[1];
+          const int z = d.c[2] + static_cast<int>(p >> 20) * d.sgn[2];
+          skip = grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z);
+          bkey = pack_key(x >> 4, y >> 4, z >> 4);
+          lin = static_cast<u32>((x & 15) | ((y & 15) << 4) | ((z & 15) << 8));
+        }
+        u64 prev = __shfl_up(bkey, 1, 64);
+        if (lane == 0) prev = carry_key;
+        const bool is_head = act && bkey != prev;
+        u32 ord = kInvalid;
+        if (is_head) {
+          const u32 slot = ht_find(L.ht_keys, L.ht_mask, bkey);
+          ord = (slot != kInvalid && L.ht_vals[slot] != kInvalid) ? L.ht_ord[slot] : kInvalid;
+        }
+        // every lane takes the ordinal of the nearest head at or below it, or the carry of the previous round
+        const u64 heads = __ballot(is_head);
+        const u64 below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        const int src = below ? (63 - __clzll(static_cast<long long>(below))) : 0;
+        const u32 head_ord = static_cast<u32>(__shfl(static_cast<int>(ord), src, 64));
+        const u32 my_ord = below ? head_ord : carry_ord;
+        if (act) {
+          rec_key[off + s] = (skip || my_ord == kInvalid) ? kInvalid : ((my_ord << 12) | lin);
+          rec_ray[off + s] = r;
+        }
+        carry_key = __shfl(bkey, 63, 64);
+        carry_ord = static_cast<u32>(__shfl(static_cast<int>(my_ord), 63, 64));
+      }
+    } else if (lane == 0) {
+      u64 last_bkey = kEmptyKey;
+      u32 last_ord = kInvalid;
+      for (u32 s = 0; s < ns; ++s) {
+        const int x = d.c[0], y = d.c[1], z = d.c[2];
+        dda_step(d);
+        u32 vid = kInvalid;
+        if (!grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z)) {
+          const u64 bkey = pack_key(x >> 4, y >> 4, z >> 4);
+          if (bkey != last_bkey) {
+            last_bkey = bkey;
+            const u32 slot = ht_find(L.ht_keys, L.ht_mask, bkey);
+            last_ord = (slot != kInvalid && L.ht_vals[slot] != kInvalid) ? L.ht_ord[slot] : kInvalid;
+          }
+          if (last_ord != kInvalid) vid = (last_ord << 12) | static_cast<u32>((x & 15) | ((y & 15) << 4) | ((z & 15) << 8));
+        }
+        rec_key[off + s] = vid;
+        rec_ray[off + s] = r;
+      }
+    }
+  }
+}
+
 // ---- apply: per voxel, the running weighted-mean / clamp update in canonical ray order -----------------
 // After the stable sort the records of one voxel are contiguous ("segment") and in ray order.
 // k_apply_eval, one wave per 64 consecutive records:
@@ -443,15 +759,15 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
     blk_voxels = 0;
   }
   __syncthreads();
-  const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
-  const u32 par = V.info->parity & 1u;
+  const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
+  const u32 par = uniform_u32(V.info->parity & 1u);
   const u32* __restrict__ rec_key = V.key[par];
   const u32* __restrict__ rec_ray = V.ray[par];
   const u32 lane = lane_id();
   const u32 n_waves = (n + 63) >> 6;
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
   u32 my_updates = 0, my_voxels = 0;
-  for (u32 wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < n_waves; wv += waves_total) {
+  for (u32 wv = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wv < n_waves; wv += waves_total) {
     const u32 wave_base = wv << 6;
     const u32 i = wave_base + lane;
     const bool in = i < n;
@@ -587,25 +903,25 @@ __global__ void __launch_bounds__(256) k_apply_long(FrameParams P, RayArrays R, 
                                                     u32* layer_err) {
   // last kernel of the frame: make this frame's error bits sticky until the host next looks
   if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
-  const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
-  const u32 n_long = n ? cnt->n_long : 0u;
-  const u32 par = V.info->parity & 1u;
+  const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
+  const u32 n_long = uniform_u32(n ? cnt->n_long : 0u);
+  const u32 par = uniform_u32(V.info->parity & 1u);
   const u32* __restrict__ rec_key = V.key[par];
   const u32* __restrict__ rec_ray = V.ray[par];
   const u32 lane = lane_id();
   const u32 n_waves = (n + 63) >> 6;
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  for (u32 j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; j < n_long; j += waves_total) {
-    const u32 start = long_start[j];
+  for (u32 j = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); j < n_long; j += waves_total) {
+    const u32 start = uniform_u32(long_start[j]);
     const VoxelRef vr = locate_voxel(L, touched_slots, rec_key[start]);
     if (!vr.ok) continue;
     Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
     const u32 w0 = start >> 6;
     // the piece at the back of the wave that holds the head
     {
-      const u32 pb = piece_back[w0];
+      const u32 pb = uniform_u32(piece_back[w0]);
       const u32 count = pb & 127u;
-      if (!((pb & kPieceFoldable) && fold_pieces(P, v, piece_wsum[2 * w0 + 1]))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count, lane, v);
+      if (!((pb & kPieceFoldable) && fold_pieces(P, v, uniform_u32(piece_wsum[2 * w0 + 1])))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count, lane, v);
     }
     // front pieces of the following waves; the segment ends with the first piece shorter than 64
     bool more = true;
@@ -892,9 +1208,17 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   // record offsets over the ray slots in use
   exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws, s);
   // allocate + stamp blocks, then emit records
-  hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->touched_slots, C, Lh->d_err, I->fh_keys, fh_mask);
-  hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->rec_key[0], I->rec_ray[0], I->rcap, C, I->sort_rec.info, I->fh_keys,
-                     fh_mask);
+  if (merged) {
+    // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
+    hipLaunchKernelGGL(k_touch_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s, P, R, L, I->touched_slots, I->rec_key[1], I->rcap, C, Lh->d_err,
+                       I->fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s, P, R, L, I->rec_key[1], I->rec_key[0], I->rec_ray[0], I->rcap, C,
+                       I->sort_rec.info, I->fh_keys, fh_mask);
+  } else {
+    hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->touched_slots, C, Lh->d_err, I->fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->rec_key[0], I->rec_ray[0], I->rcap, C, I->sort_rec.info, I->fh_keys,
+                       fh_mask);
+  }
   const u32 rec_hint = I->hint_records ? std::min(I->hint_records, I->rcap) : std::min<u32>(I->rcap, std::max<u32>(1u << 20, n * 4u));
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits
   (void)radix_sort_pairs<11>(I->rec_key[0], I->rec_ray[0], I->rec_key[1], I->rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, s);
