@@ -752,11 +752,12 @@ __device__ __forceinline__ bool foldable_update(const FrameParams& P, float sdf,
 
 __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
                                                     u32* __restrict__ piece_front, u32* __restrict__ piece_back, u32* __restrict__ piece_wsum,
-                                                    u32* __restrict__ long_start, Counters* cnt) {
-  __shared__ u32 blk_updates, blk_voxels;
+                                                    Counters* cnt) {
+  __shared__ u32 blk_updates, blk_voxels, blk_long;
   if (threadIdx.x == 0) {
     blk_updates = 0;
     blk_voxels = 0;
+    blk_long = 0;
   }
   __syncthreads();
   const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
@@ -766,7 +767,7 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
   const u32 lane = lane_id();
   const u32 n_waves = (n + 63) >> 6;
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  u32 my_updates = 0, my_voxels = 0;
+  u32 my_updates = 0, my_voxels = 0, my_long = 0;
   for (u32 wv = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wv < n_waves; wv += waves_total) {
     const u32 wave_base = wv << 6;
     const u32 i = wave_base + lane;
@@ -794,7 +795,7 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
     const u64 bmask = __ballot(boundary);
     const u64 later = (lane == 63) ? 0ull : (bmask >> (lane + 1));
     u32 len = 0;
-    bool is_long = false;
+    bool runs_on = false;  // the segment of this head continues in the next wave
     if (head) {
       if (later) {
         len = static_cast<u32>(__ffsll(static_cast<long long>(later)));
@@ -803,9 +804,35 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
         if (nxt >= n || rec_key[nxt] != key)
           len = min(nxt, n) - i;
         else
-          is_long = true;
+          runs_on = true;
       }
     }
+    // A segment that merely straddles the wave boundary (ends inside the next wave) is finished here: the few
+    // records of its tail are evaluated by this wave too.  Only segments that cover the whole next wave are "long".
+    const u64 omask = __ballot(runs_on);
+    bool strad = false;
+    float sdf2 = 0.0f, uw2 = 0.0f;
+    u32 color2 = 0, ll = 0;
+    if (omask) {
+      ll = static_cast<u32>(__ffsll(static_cast<long long>(omask))) - 1u;
+      const u32 lkey = static_cast<u32>(__builtin_amdgcn_readlane(key, ll));
+      const u32 j = wave_base + 64 + lane;
+      const bool in2 = (j < n) && (rec_key[j] == lkey);
+      const u32 e2 = static_cast<u32>(__popcll(__ballot(in2)));  // the tail is contiguous: lanes [0, e2)
+      if (e2 < 64) {
+        strad = true;
+        const int gx = __builtin_amdgcn_readlane(vr.gx, ll), gy = __builtin_amdgcn_readlane(vr.gy, ll), gz = __builtin_amdgcn_readlane(vr.gz, ll);
+        if (in2) {
+          const u32 r = rec_ray[j];
+          const F3 pg{R.px[r], R.py[r], R.pz[r]};
+          sdf2 = compute_sdf(P, pg, gx, gy, gz);
+          uw2 = update_weight(P, sdf2, R.w[r]);
+          color2 = R.color[r];
+        }
+        if (lane == ll) len = (64u - ll) + e2;
+      }
+    }
+    const bool is_long = runs_on && !strad;
     // ---- 2. short segments: head lanes replay their records in order ----------------------------------
     const bool run_short = head && !is_long && vr.ok;
     Voxel v{0.0f, 0.0f, 0u};
@@ -818,10 +845,21 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(static_cast<int>(max_len), off, 64)));
     for (u32 k = 0; k < max_len; ++k) {
-      const int src = static_cast<int>((lane + k) & 63u);
-      const float s_k = __shfl(sdf, src, 64);
-      const float u_k = __shfl(uw, src, 64);
-      const u32 c_k = static_cast<u32>(__shfl(static_cast<int>(color), src, 64));
+      const u32 idx = lane + k;
+      const int src = static_cast<int>(idx & 63u);
+      float s_k = __shfl(sdf, src, 64);
+      float u_k = __shfl(uw, src, 64);
+      u32 c_k = static_cast<u32>(__shfl(static_cast<int>(color), src, 64));
+      if (strad && k + ll >= 64u) {  // wave-uniform: only then can a lane reach past the wave (lane ll is the only one that does)
+        const float s_2 = __shfl(sdf2, src, 64);
+        const float u_2 = __shfl(uw2, src, 64);
+        const u32 c_2 = static_cast<u32>(__shfl(static_cast<int>(color2), src, 64));
+        if (idx >= 64u) {
+          s_k = s_2;
+          u_k = u_2;
+          c_k = c_2;
+        }
+      }
       if (run_short && k < len) update_voxel(P, v, s_k, u_k, c_k);
     }
     if (run_short) {
@@ -844,21 +882,23 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
         piece_wsum[2 * wv] = wsum;
       }
     }
-    // back piece: the long segment (at most one) that starts in this wave
+    // back piece: the long segment (at most one) that starts in this wave; 0 = none
     const u64 lmask = __ballot(is_long);
     if (lmask) {
-      const u32 ll = static_cast<u32>(__ffsll(static_cast<long long>(lmask))) - 1u;
-      const u64 bm = ~((1ull << ll) - 1ull);
+      const u32 lh = static_cast<u32>(__ffsll(static_cast<long long>(lmask))) - 1u;
+      const u64 bm = ~((1ull << lh) - 1ull);
       const bool all_fold = (__ballot(fold) & bm) == bm;
-      const float wb = (lane >= ll) ? uw : 0.0f;
+      const float wb = (lane >= lh) ? uw : 0.0f;
       u32 wsum = all_fold ? static_cast<u32>(wb) : 0u;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) wsum += static_cast<u32>(__shfl_xor(static_cast<int>(wsum), off, 64));
-      if (lane == ll) {
-        piece_back[wv] = (64u - ll) | (all_fold ? kPieceFoldable : 0u);
+      if (lane == lh) {
+        piece_back[wv] = (64u - lh) | (all_fold ? kPieceFoldable : 0u);
         piece_wsum[2 * wv + 1] = wsum;
-        long_start[atomicAdd(&cnt->n_long, 1u)] = i;
       }
+      my_long += 1;
+    } else if (lane == 0) {
+      piece_back[wv] = 0;
     }
     my_updates += static_cast<u32>(__popcll(__ballot(valid)));
     my_voxels += static_cast<u32>(__popcll(__ballot(head)));
@@ -866,11 +906,13 @@ __global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, 
   if (lane == 0) {
     if (my_updates) atomicAdd(&blk_updates, my_updates);
     if (my_voxels) atomicAdd(&blk_voxels, my_voxels);
+    if (my_long) atomicAdd(&blk_long, my_long);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (blk_updates) atomicAdd(&cnt->n_updates, blk_updates);
     if (blk_voxels) atomicAdd(&cnt->n_voxels, blk_voxels);
+    if (blk_long) atomicAdd(&cnt->n_long, blk_long);
   }
 }
 
@@ -899,66 +941,69 @@ __device__ __forceinline__ bool fold_pieces(const FrameParams& P, Voxel& v, u32 
 
 __global__ void __launch_bounds__(256) k_apply_long(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
                                                     const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
-                                                    const u32* __restrict__ piece_wsum, const u32* __restrict__ long_start, const Counters* cnt,
-                                                    u32* layer_err) {
+                                                    const u32* __restrict__ piece_wsum, const Counters* cnt, u32* layer_err) {
   // last kernel of the frame: make this frame's error bits sticky until the host next looks
   if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
   const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
-  const u32 n_long = uniform_u32(n ? cnt->n_long : 0u);
+  if (n == 0 || uniform_u32(cnt->n_long) == 0) return;
   const u32 par = uniform_u32(V.info->parity & 1u);
   const u32* __restrict__ rec_key = V.key[par];
   const u32* __restrict__ rec_ray = V.ray[par];
   const u32 lane = lane_id();
   const u32 n_waves = (n + 63) >> 6;
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  for (u32 j = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); j < n_long; j += waves_total) {
-    const u32 start = uniform_u32(long_start[j]);
-    const VoxelRef vr = locate_voxel(L, touched_slots, rec_key[start]);
-    if (!vr.ok) continue;
-    Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
-    const u32 w0 = start >> 6;
-    // the piece at the back of the wave that holds the head
-    {
-      const u32 pb = uniform_u32(piece_back[w0]);
-      const u32 count = pb & 127u;
-      if (!((pb & kPieceFoldable) && fold_pieces(P, v, uniform_u32(piece_wsum[2 * w0 + 1])))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count, lane, v);
-    }
-    // front pieces of the following waves; the segment ends with the first piece shorter than 64
-    bool more = true;
-    for (u32 wbase = w0 + 1; more && wbase < n_waves; wbase += 64) {
-      const u32 w = wbase + lane;
-      const u32 pf = (w < n_waves) ? piece_front[w] : 0u;
-      const u32 ws = (w < n_waves) ? piece_wsum[2 * w] : 0u;
-      const u32 count = pf & 127u;
-      const u64 end_mask = __ballot(count < 64u);
-      const u32 n_use = end_mask ? static_cast<u32>(__ffsll(static_cast<long long>(end_mask))) : 64u;  // pieces [0, n_use) belong to the segment
-      if (end_mask) more = false;
-      const u64 use_mask = (n_use == 64) ? ~0ull : ((1ull << n_use) - 1ull);
-      const u64 hard_mask = __ballot(!(pf & kPieceFoldable)) & use_mask;  // pieces that need a record-by-record replay
-      u32 pos = 0;
-      while (pos < n_use) {
-        const u64 hard_from = hard_mask >> pos;
-        const u32 run = hard_from ? static_cast<u32>(__ffsll(static_cast<long long>(hard_from))) - 1u : (n_use - pos);  // foldable pieces ahead
-        if (run > 0) {
-          // total weight of pieces [pos, pos + run)
-          u32 t = (lane >= pos && lane < pos + run) ? ws : 0u;
+  // every record wave with a back piece owns one long segment; 64 record waves are inspected per step
+  for (u32 wb0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6; wb0 < n_waves; wb0 += waves_total << 6) {
+    const u32 pbl = (wb0 + lane < n_waves) ? piece_back[wb0 + lane] : 0u;
+    u64 todo = __ballot(pbl != 0u);
+    while (todo) {
+      const u32 bit = static_cast<u32>(__ffsll(static_cast<long long>(todo))) - 1u;
+      todo &= todo - 1ull;
+      const u32 w0 = wb0 + bit;
+      const u32 pb = static_cast<u32>(__builtin_amdgcn_readlane(pbl, bit));
+      const u32 count0 = pb & 127u;
+      const u32 start = (w0 << 6) + 64u - count0;
+      const VoxelRef vr = locate_voxel(L, touched_slots, uniform_u32(rec_key[start]));
+      if (!vr.ok) continue;
+      Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
+      // the piece at the back of the wave that holds the head
+      if (!((pb & kPieceFoldable) && fold_pieces(P, v, uniform_u32(piece_wsum[2 * w0 + 1])))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count0, lane, v);
+      // front pieces of the following waves; the segment ends with the first piece shorter than 64
+      bool more = true;
+      for (u32 wbase = w0 + 1; more && wbase < n_waves; wbase += 64) {
+        const u32 w = wbase + lane;
+        const u32 pf = (w < n_waves) ? piece_front[w] : 0u;
+        const u32 ws = (w < n_waves) ? piece_wsum[2 * w] : 0u;
+        const u32 count = pf & 127u;
+        const u64 end_mask = __ballot(count < 64u);
+        const u32 n_use = end_mask ? static_cast<u32>(__ffsll(static_cast<long long>(end_mask))) : 64u;  // pieces [0, n_use) belong to the segment
+        if (end_mask) more = false;
+        const u64 use_mask = (n_use == 64) ? ~0ull : ((1ull << n_use) - 1ull);
+        const u64 hard_mask = __ballot(!(pf & kPieceFoldable)) & use_mask;  // pieces that need a record-by-record replay
+        u32 pos = 0;
+        while (pos < n_use) {
+          const u64 hard_from = hard_mask >> pos;
+          const u32 run = hard_from ? static_cast<u32>(__ffsll(static_cast<long long>(hard_from))) - 1u : (n_use - pos);  // foldable pieces ahead
+          if (run > 0) {
+            u32 t = (lane >= pos && lane < pos + run) ? ws : 0u;  // total weight of pieces [pos, pos + run)
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) t += static_cast<u32>(__shfl_xor(static_cast<int>(t), off, 64));
-          if (fold_pieces(P, v, t)) {
-            pos += run;
-            continue;
+            for (int off = 32; off > 0; off >>= 1) t += static_cast<u32>(__shfl_xor(static_cast<int>(t), off, 64));
+            if (fold_pieces(P, v, t)) {
+              pos += run;
+              continue;
+            }
           }
+          // replay piece `pos` (hard, or the voxel is not in a foldable state yet)
+          const u32 cnt_p = static_cast<u32>(__builtin_amdgcn_readlane(count, pos));
+          if (cnt_p) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, (wbase + pos) << 6, cnt_p, lane, v);
+          pos += 1;
         }
-        // replay piece `pos` (hard, or the voxel is not in a foldable state yet)
-        const u32 cnt_p = static_cast<u32>(__builtin_amdgcn_readlane(count, pos));
-        if (cnt_p) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, (wbase + pos) << 6, cnt_p, lane, v);
-        pos += 1;
       }
-    }
-    if (lane == 0) {
-      vr.ptr[0] = __float_as_uint(v.d);
-      vr.ptr[1] = __float_as_uint(v.w);
-      vr.ptr[2] = v.c;
+      if (lane == 0) {
+        vr.ptr[0] = __float_as_uint(v.d);
+        vr.ptr[1] = __float_as_uint(v.w);
+        vr.ptr[2] = v.c;
+      }
     }
   }
 }
@@ -1230,8 +1275,8 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipEventRecord(e0, s));
   }
   hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum,
-                     I->long_start, C);
-  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum, I->long_start, C,
+                     C);
+  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum, C,
                      Lh->d_err);
   if (I->profiling) {
     COX_HIP(hipEventRecord(e1, s));
