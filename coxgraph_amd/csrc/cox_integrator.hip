@@ -167,7 +167,9 @@ __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const floa
       }
     }
   }
-  u32 slot = kInvalid;
+  // group the lanes by key (ALU only), then let all group leaders touch memory at the same time
+  u32 my_leader = lane, group_min = kInvalid;
+  bool is_leader = false;
   u64 todo = __ballot(valid);
   while (todo) {
     const u32 leader = static_cast<u32>(__ffsll(static_cast<long long>(todo))) - 1u;
@@ -178,19 +180,24 @@ __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const floa
     u32 mn = mine ? seq : kInvalid;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mn = min(mn, static_cast<u32>(__shfl_xor(static_cast<int>(mn), off, 64)));
-    u32 sl = kInvalid;
+    if (mine) my_leader = leader;
     if (lane == leader) {
-      bool fresh;
-      sl = ht_insert(fh_keys, fh_mask, k, &fresh);
-      if (sl == kInvalid)
-        atomicOr(&cnt->err, kErrTable);
-      else if (__hip_atomic_load(&fh_first[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > mn)
-        atomicMin(&fh_first[sl], mn);  // a stale (larger) value read above only costs this atomic
+      is_leader = true;
+      group_min = mn;
     }
-    sl = static_cast<u32>(__builtin_amdgcn_readlane(sl, leader));
-    if (mine) slot = sl;
     todo &= ~peers;
   }
+  u32 sl = kInvalid;
+  if (is_leader) {
+    bool fresh;
+    sl = ht_insert(fh_keys, fh_mask, key, &fresh);
+    if (sl == kInvalid)
+      atomicOr(&cnt->err, kErrTable);
+    else if (__hip_atomic_load(&fh_first[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > group_min)
+      atomicMin(&fh_first[sl], group_min);  // a stale (larger) value read above only costs this atomic
+  }
+  const u32 got = static_cast<u32>(__shfl(static_cast<int>(sl), static_cast<int>(my_leader), 64));
+  const u32 slot = valid ? got : kInvalid;
   if (idx < P.n_points) pslot[seq] = slot;  // kInvalid for points that are not integrated
   const u64 m = __ballot(valid && slot != kInvalid);
   if (lane == 0 && m) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
@@ -1042,13 +1049,19 @@ struct cox_integrator {
   cox_layer* layer = nullptr;
   cox_tsdf_config cfg;
   int method = 0;
-  hipStream_t stream = nullptr;
+  // Two streams form a two-stage pipeline across frames: stage A (ray generation: depends only on the frame's
+  // input) of frame t+1 runs beside stage B (layer update) of frame t.  Everything stage A hands to stage B is
+  // double-buffered (index = frame number & 1).
+  hipStream_t stream = nullptr;   // stage B, also the stream the host API copies on
+  hipStream_t stream_a = nullptr; // stage A
+  hipEvent_t ev_a_done[2] = {nullptr, nullptr}, ev_b_done[2] = {nullptr, nullptr};
+  bool b_used[2] = {false, false};
   // point-sized workspace
   u32 pcap = 0;
-  RayArrays rays{};
+  RayArrays rays2[2] = {};
   u32 *pslot = nullptr, *skey[2] = {nullptr, nullptr}, *sval[2] = {nullptr, nullptr}, *head = nullptr, *bstart = nullptr;
-  u64* fh_keys = nullptr;  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
-  u32* fh_first = nullptr;
+  u64* fh_keys2[2] = {nullptr, nullptr};  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
+  u32* fh_first2[2] = {nullptr, nullptr};
   u32 fh_cap = 0;
   float* own_xyz = nullptr;  // staging for host / depth inputs
   uint8_t* own_rgba = nullptr;
@@ -1057,12 +1070,13 @@ struct cox_integrator {
   u32 rcap = 0;
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
   u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
-  u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr, *long_start = nullptr;
+  u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
   u32* touched_slots = nullptr;  // [layer ht_cap]
   SortWorkspace sort_pts, sort_rec;
-  ScanWorkspace scanws;
+  ScanWorkspace scanws_a, scanws_b;
   u32 scan_cap = 0;
-  Counters* d_cnt = nullptr;
+  Counters* d_cnt2 = nullptr;  // two frames in flight
+  u32* d_depth_n = nullptr;    // point count of the depth front end
   Counters* h_ring = nullptr;  // pinned, kStatRing entries
   uint64_t frame_no = 0;       // frames enqueued
   uint64_t counts_frame = 0;   // frame whose end-of-frame counters were last enqueued (0 = none)
@@ -1115,17 +1129,21 @@ static u32 max_steps_per_ray(const cox_integrator* I) {
 
 static int ensure_capacity(cox_integrator* I, u32 n) {
   if (n <= I->pcap) return COX_OK;
+  COX_HIP(hipStreamSynchronize(I->stream_a));
   COX_HIP(hipStreamSynchronize(I->stream));
   const u32 cap = std::max<u32>(n, 1024);
-  COX_TRY(dev_realloc(&I->rays.px, cap));
-  COX_TRY(dev_realloc(&I->rays.py, cap));
-  COX_TRY(dev_realloc(&I->rays.pz, cap));
-  COX_TRY(dev_realloc(&I->rays.w, cap));
-  COX_TRY(dev_realloc(&I->rays.color, cap));
-  COX_TRY(dev_realloc(&I->rays.flags, cap));
-  COX_TRY(dev_realloc(&I->rays.key, cap));
-  COX_TRY(dev_realloc(&I->rays.nsteps, cap));
-  COX_TRY(dev_realloc(&I->rays.rec_off, cap));
+  for (int b = 0; b < 2; ++b) {
+    RayArrays& R = I->rays2[b];
+    COX_TRY(dev_realloc(&R.px, cap));
+    COX_TRY(dev_realloc(&R.py, cap));
+    COX_TRY(dev_realloc(&R.pz, cap));
+    COX_TRY(dev_realloc(&R.w, cap));
+    COX_TRY(dev_realloc(&R.color, cap));
+    COX_TRY(dev_realloc(&R.flags, cap));
+    COX_TRY(dev_realloc(&R.key, cap));
+    COX_TRY(dev_realloc(&R.nsteps, cap));
+    COX_TRY(dev_realloc(&R.rec_off, cap));
+  }
   COX_TRY(dev_realloc(&I->pslot, cap));
   for (int k = 0; k < 2; ++k) {
     COX_TRY(dev_realloc(&I->skey[k], cap));
@@ -1136,9 +1154,11 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   COX_TRY(dev_realloc(&I->own_xyz, static_cast<size_t>(cap) * 3));
   COX_TRY(dev_realloc(&I->own_rgba, static_cast<size_t>(cap) * 4));
   COX_TRY(dev_realloc(&I->depth_flag, cap));
-  I->fh_cap = next_pow2(2ull * cap);
-  COX_TRY(dev_realloc(&I->fh_keys, static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
-  I->fh_first = reinterpret_cast<u32*>(I->fh_keys + I->fh_cap);
+  I->fh_cap = next_pow2(static_cast<u64>(cap) + cap / 2);  // load factor <= 2/3 even if every point is its own bundle
+  for (int b = 0; b < 2; ++b) {
+    COX_TRY(dev_realloc(&I->fh_keys2[b], static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
+    I->fh_first2[b] = reinterpret_cast<u32*>(I->fh_keys2[b] + I->fh_cap);
+  }
   COX_TRY(alloc_sort_ws(&I->sort_pts, cap));
   // records: the worst case (every ray at maximum length) always fits, so a frame can never overflow
   // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
@@ -1154,11 +1174,11 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   COX_TRY(dev_realloc(&I->piece_front, wave_cap));
   COX_TRY(dev_realloc(&I->piece_back, wave_cap));
   COX_TRY(dev_realloc(&I->piece_wsum, static_cast<size_t>(wave_cap) * 2));
-  COX_TRY(dev_realloc(&I->long_start, wave_cap));
   COX_TRY(alloc_sort_ws(&I->sort_rec, rcap));
   const u32 need_scan = scan_num_blocks(cap) + 2;
   if (need_scan > I->scan_cap) {
-    COX_TRY(dev_realloc(&I->scanws.block_sums, need_scan));
+    COX_TRY(dev_realloc(&I->scanws_a.block_sums, need_scan));
+    COX_TRY(dev_realloc(&I->scanws_b.block_sums, need_scan));
     I->scan_cap = need_scan;
   }
   I->rcap = rcap;
@@ -1213,76 +1233,86 @@ static void refresh_hints(cox_integrator* I) {
 // the end of the frame
 static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
   cox_layer* Lh = I->layer;
-  hipStream_t s = I->stream;
   COX_TRY(ensure_capacity(I, n));
   FrameParams P = make_params(I, T, n, freespace);
   P.frame_id = ++Lh->frame_id;
   LayerView L{Lh->voxels, Lh->ht_keys, Lh->ht_vals, Lh->ht_stamp, Lh->ht_ord, Lh->block_keys, Lh->d_nblocks, Lh->ht_cap - 1, static_cast<u32>(Lh->capacity)};
-  RayArrays R = I->rays;
-  Counters* C = I->d_cnt;
-  COX_HIP(hipMemsetAsync(C, 0, sizeof(Counters), s));
   I->frame_no += 1;
+  const int buf = static_cast<int>(I->frame_no & 1u);
+  hipStream_t sa = I->stream_a, sb = I->stream;
+  RayArrays R = I->rays2[buf];
+  Counters* C = I->d_cnt2 + buf;
+  u64* fh_keys = I->fh_keys2[buf];
+  u32* fh_first = I->fh_first2[buf];
   I->last = cox_frame_stats{};
   I->last.n_points = n;
   I->last_has_counts = false;
   if (n == 0) return COX_OK;
   refresh_hints(I);
 
+  // ---------------- stage A: rays of this frame (input only) ----------------
+  if (I->b_used[buf]) COX_HIP(hipStreamWaitEvent(sa, I->ev_b_done[buf], 0));  // frame t-2 is done with this buffer set
+  COX_HIP(hipMemsetAsync(C, 0, sizeof(Counters), sa));
   const u32 fh_mask = I->fh_cap - 1;
   const bool merged = I->method == COX_METHOD_MERGED;
   u32 ray_hint;
   if (merged) {
     const u32 np2 = next_pow2(static_cast<u64>(n) + 1);
-    COX_HIP(hipMemsetAsync(I->fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
-    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, P, xyz, I->fh_keys, I->fh_first, fh_mask, I->pslot, C);
-    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, n, np2, I->fh_keys, I->fh_first, I->pslot, I->skey[0], I->sval[0]);
+    COX_HIP(hipMemsetAsync(fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, sa));
+    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, sa, P, xyz, fh_keys, fh_first, fh_mask, I->pslot, C);
+    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, sa, n, np2, fh_keys, fh_first, I->pslot, I->skey[0], I->sval[0]);
     const int kbits = ceil_log2(np2) + 1;  // + clearing bit; kInvalid's low bits exceed every valid key
-    const int cur = radix_sort_pairs<11>(I->skey[0], I->sval[0], I->skey[1], I->sval[1], nullptr, n, n, kbits, false, 0, I->sort_pts, s);
+    const int cur = radix_sort_pairs<11>(I->skey[0], I->sval[0], I->skey[1], I->sval[1], nullptr, n, n, kbits, false, 0, I->sort_pts, sa);
     const u32* sk = I->skey[cur];
     const u32* sv = I->sval[cur];
-    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, s, n, sk, I->head);
+    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, sa, n, sk, I->head);
     // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
-    exclusive_scan_u32(I->head, I->head, nullptr, n, n, &C->n_rays, I->scanws, s);
-    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, n, sk, I->head, I->bstart, C);
+    exclusive_scan_u32(I->head, I->head, nullptr, n, n, &C->n_rays, I->scanws_a, sa);
+    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, sa, n, sk, I->head, I->bstart, C);
     ray_hint = I->hint_rays ? std::min(I->hint_rays, n) : std::min<u32>(n, 16384);
-    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s, P, np2, xyz, rgba, sk, sv, I->bstart, R, C);
+    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, sa, P, np2, xyz, rgba, sk, sv, I->bstart, R, C);
   } else {
-    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, P, xyz, rgba, R, C);
+    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, sa, P, xyz, rgba, R, C);
     ray_hint = n;
   }
+  COX_HIP(hipEventRecord(I->ev_a_done[buf], sa));
+
+  // ---------------- stage B: update the layer ----------------
+  COX_HIP(hipStreamWaitEvent(sb, I->ev_a_done[buf], 0));
   // record offsets over the ray slots in use
-  exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws, s);
+  exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws_b, sb);
   // allocate + stamp blocks, then emit records
   if (merged) {
     // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
-    hipLaunchKernelGGL(k_touch_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s, P, R, L, I->touched_slots, I->rec_key[1], I->rcap, C, Lh->d_err,
-                       I->fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s, P, R, L, I->rec_key[1], I->rec_key[0], I->rec_ray[0], I->rcap, C,
-                       I->sort_rec.info, I->fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_touch_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, sb, P, R, L, I->touched_slots, I->rec_key[1], I->rcap, C, Lh->d_err,
+                       fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, sb, P, R, L, I->rec_key[1], I->rec_key[0], I->rec_ray[0], I->rcap, C,
+                       I->sort_rec.info, fh_keys, fh_mask);
   } else {
-    hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->touched_slots, C, Lh->d_err, I->fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, s, P, R, L, I->rec_key[0], I->rec_ray[0], I->rcap, C, I->sort_rec.info, I->fh_keys,
+    hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, sb, P, R, L, I->touched_slots, C, Lh->d_err, fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, sb, P, R, L, I->rec_key[0], I->rec_ray[0], I->rcap, C, I->sort_rec.info, fh_keys,
                        fh_mask);
   }
   const u32 rec_hint = I->hint_records ? std::min(I->hint_records, I->rcap) : std::min<u32>(I->rcap, std::max<u32>(1u << 20, n * 4u));
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits
-  (void)radix_sort_pairs<11>(I->rec_key[0], I->rec_ray[0], I->rec_key[1], I->rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, s);
+  (void)radix_sort_pairs<11>(I->rec_key[0], I->rec_ray[0], I->rec_key[1], I->rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, sb);
   RecordView V{{I->rec_key[0], I->rec_key[1]}, {I->rec_ray[0], I->rec_ray[1]}, I->sort_rec.info, &C->n_records};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->profiling) {
     COX_HIP(hipEventCreate(&e0));
     COX_HIP(hipEventCreate(&e1));
-    COX_HIP(hipEventRecord(e0, s));
+    COX_HIP(hipEventRecord(e0, sb));
   }
-  hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum,
+  hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, sb, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum,
                      C);
-  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum, C,
-                     Lh->d_err);
+  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, sb, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum, C, Lh->d_err);
   if (I->profiling) {
-    COX_HIP(hipEventRecord(e1, s));
+    COX_HIP(hipEventRecord(e1, sb));
     I->apply_events.emplace_back(e0, e1);
   }
-  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], C, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], C, sizeof(Counters), hipMemcpyDeviceToHost, sb));
+  COX_HIP(hipEventRecord(I->ev_b_done[buf], sb));
+  I->b_used[buf] = true;
   I->counts_frame = I->frame_no;
   I->last_has_counts = true;
   COX_HIP(hipGetLastError());
@@ -1291,6 +1321,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
 
 // wait for the stream, fold the last frame's counters into the stats, return deferred errors
 static int integrator_finish(cox_integrator* I) {
+  COX_HIP(hipStreamSynchronize(I->stream_a));
   COX_HIP(hipStreamSynchronize(I->stream));
   u32 err = 0;
   if (I->last_has_counts) {
@@ -1337,9 +1368,15 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   I->method = method;
   int st = COX_OK;
   if (hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
-  if (st == COX_OK && hipMalloc(reinterpret_cast<void**>(&I->d_cnt), sizeof(Counters)) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK && hipStreamCreateWithFlags(&I->stream_a, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  for (int b = 0; b < 2 && st == COX_OK; ++b) {
+    if (hipEventCreateWithFlags(&I->ev_a_done[b], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
+    if (st == COX_OK && hipEventCreateWithFlags(&I->ev_b_done[b], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  }
+  if (st == COX_OK && hipMalloc(reinterpret_cast<void**>(&I->d_cnt2), 2 * sizeof(Counters)) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK) st = dev_realloc(&I->d_depth_n, 1);
   if (st == COX_OK) st = dev_realloc(&I->touched_slots, layer->ht_cap);  // one entry per block key the table can hold
   if (st == COX_OK) {
     memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
@@ -1356,19 +1393,29 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
 void cox_integrator_destroy(cox_integrator_t* I) {
   if (!I) return;
   (void)hipSetDevice(I->layer->device);
+  if (I->stream_a) (void)hipStreamSynchronize(I->stream_a);
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   for (auto& ev : I->apply_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
-  void* ptrs[] = {I->rays.px, I->rays.py, I->rays.pz, I->rays.w, I->rays.color, I->rays.flags, I->rays.key, I->rays.nsteps, I->rays.rec_off, I->pslot,
-                  I->skey[0], I->skey[1], I->sval[0], I->sval[1], I->head, I->bstart, I->fh_keys, I->own_xyz, I->own_rgba, I->depth_flag, I->rec_key[0],
-                  I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->piece_front, I->piece_back, I->piece_wsum, I->long_start, I->touched_slots,
-                  I->sort_pts.counts, I->sort_pts.totals, I->sort_pts.info, I->sort_rec.counts, I->sort_rec.totals, I->sort_rec.info, I->scanws.block_sums,
-                  I->d_cnt};
+  std::vector<void*> ptrs = {I->pslot, I->skey[0], I->skey[1], I->sval[0], I->sval[1], I->head, I->bstart, I->own_xyz, I->own_rgba, I->depth_flag,
+                             I->rec_key[0], I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->piece_front, I->piece_back, I->piece_wsum, I->touched_slots,
+                             I->sort_pts.counts, I->sort_pts.totals, I->sort_pts.info, I->sort_rec.counts, I->sort_rec.totals, I->sort_rec.info,
+                             I->scanws_a.block_sums, I->scanws_b.block_sums, I->d_cnt2, I->d_depth_n};
+  for (int b = 0; b < 2; ++b) {
+    const RayArrays& R = I->rays2[b];
+    for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
+                    static_cast<void*>(R.flags), static_cast<void*>(R.key), static_cast<void*>(R.nsteps), static_cast<void*>(R.rec_off),
+                    static_cast<void*>(I->fh_keys2[b])})
+      ptrs.push_back(p);
+    if (I->ev_a_done[b]) (void)hipEventDestroy(I->ev_a_done[b]);
+    if (I->ev_b_done[b]) (void)hipEventDestroy(I->ev_b_done[b]);
+  }
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
+  if (I->stream_a) (void)hipStreamDestroy(I->stream_a);
   if (I->stream) (void)hipStreamDestroy(I->stream);
   delete I;
 }
@@ -1385,10 +1432,10 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
-  COX_HIP(hipStreamSynchronize(I->stream));  // the staging buffers may still feed an earlier frame
+  COX_HIP(hipStreamSynchronize(I->stream_a));  // the staging buffers may still feed an earlier frame
   if (n) {
-    COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->stream));
-    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->stream));
+    COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->stream_a));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->stream_a));
   }
   COX_TRY(integrate_device(I, T_G_C, I->own_xyz, rgba ? I->own_rgba : nullptr, static_cast<u32>(n), freespace));
   return integrator_finish(I);
@@ -1400,15 +1447,15 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   COX_HIP(hipSetDevice(I->layer->device));
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
-  hipStream_t s = I->stream;
+  hipStream_t s = I->stream_a;
   COX_HIP(hipStreamSynchronize(s));  // staging buffers
   hipLaunchKernelGGL(k_depth_flags, grid_for(n), dim3(256), 0, s, depth_dev, n, I->depth_flag);
-  exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, &I->d_cnt->n_depth_points, I->scanws, s);
+  exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, I->d_depth_n, I->scanws_a, s);
   hipLaunchKernelGGL(k_depth_points, grid_for(n), dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz,
                      I->own_rgba);
   // the point count feeds the "mixed" visiting order, which is a function of N: it has to reach the host
   Counters* tmp = &I->h_ring[0];
-  COX_HIP(hipMemcpyAsync(&tmp->n_depth_points, &I->d_cnt->n_depth_points, sizeof(u32), hipMemcpyDeviceToHost, s));
+  COX_HIP(hipMemcpyAsync(&tmp->n_depth_points, I->d_depth_n, sizeof(u32), hipMemcpyDeviceToHost, s));
   COX_HIP(hipStreamSynchronize(s));
   const u32 n_pts = tmp->n_depth_points;
   return integrate_device(I, T_G_C, I->own_xyz, I->own_rgba, n_pts, 0);
@@ -1425,6 +1472,7 @@ int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
   COX_ENTRY();
   if (!I || !stats) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
+  COX_HIP(hipStreamSynchronize(I->stream_a));
   COX_HIP(hipStreamSynchronize(I->stream));
   if (I->last_has_counts) {
     const Counters& c = I->h_ring[I->frame_no % kStatRing];

@@ -121,9 +121,9 @@ static inline void exclusive_scan_u32(const u32* in, u32* out, const u32* d_n, u
 // ------------------------------------------------------------------------------------------------
 constexpr int kRsThreads = 256;
 constexpr int kRsWaves = 4;
-constexpr int kRsRounds = 16;
-constexpr int kRsWaveTile = 64 * kRsRounds;      // 1024 elements per wave
-constexpr int kRsTile = kRsWaveTile * kRsWaves;  // 4096 elements per tile
+constexpr int kRsRounds = 8;
+constexpr int kRsWaveTile = 64 * kRsRounds;      // 512 elements per wave
+constexpr int kRsTile = kRsWaveTile * kRsWaves;  // 2048 elements per tile (smaller: the 2048-bin histograms dominate; larger: too few workgroups)
 constexpr int kRsMaxPasses = 4;
 
 // device-side description of one sort
