@@ -194,6 +194,12 @@ class Integrator:
     def set_profiling(self, on=True):
         self.eng.check(self.eng.fn("integrator_set_profiling")(self.h, C.c_int(int(on))), "integrator_set_profiling")
 
+    def stage_times(self, reset=False):
+        """{'merge': (ms, launches), 'apply': (ms, launches)} measured with HIP events on the kernels' own streams."""
+        ms, n = (C.c_double * 2)(), (C.c_uint64 * 2)()
+        self.eng.check(self.eng.fn("integrator_stage_times")(self.h, ms, n, C.c_int(int(reset))), "integrator_stage_times")
+        return {"merge": (float(ms[0]), int(n[0])), "apply": (float(ms[1]), int(n[1]))}
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         self.eng.check(self.eng.fn("integrator_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))),

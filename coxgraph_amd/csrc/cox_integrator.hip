@@ -228,16 +228,17 @@ __global__ void __launch_bounds__(256) k_bundle_starts(u32 n, const u32* __restr
   if (k != kInvalid && (i == 0 || skey[i - 1] != k)) bstart[head_scan[i]] = i;
 }
 
-// wave = bundle: the sequential weighted mean of its points in visiting order, bit-exact with the
+// two waves per bundle: the sequential weighted mean of its points in visiting order, bit-exact with the
 // single-threaded reference loop
 //     merged = (merged * W + p * w) / (W + w);  colour = blend(colour, W, c, w);  W += w
-// Written as one recurrence  val <- post((val * M_k + A_k) / D_k)  per component:
-//     x, y, z:     M = W_k,           A = p * w,             D = W_k + w,  post = identity
-//     r, g, b, a:  M = W_k / (W_k+w), A = c * (w / (W_k+w)), D = 1,        post = round   (x / 1 is exact)
-// 64 points at a time are gathered in parallel and their (M, A, D) operands -- everything that does not depend
-// on the running value -- are computed lane-parallel into an LDS table [point][component]; lanes 0-6 then each
-// carry one component through the dependent chain with one LDS read per step and no branches.  Skipped points
-// (w < eps, or anything after the first point of a clearing bundle) are the identity step (M, A, D) = (1, 0, 1).
+// Each component is a recurrence  val <- f_k(val)  whose operands do not depend on the running value:
+//     x, y, z (wave 0):     val <- (val * W_k + p * w) / (W_k + w)                   one IEEE divide per step
+//     a, b, g, r (wave 1):  val <- round(val * (W_k/(W_k+w)) + c * (w/(W_k+w)))      multiply-add-round per step
+// 64 points at a time are gathered in parallel and their operands are computed lane-parallel into an LDS table
+// [point][component]; lanes 0-3 then carry one component each through the dependent chain with one (prefetched)
+// LDS read per step and no branches.  The chain length is the bundle size, so the two chains of a big bundle run
+// side by side on different SIMDs instead of back to back.  Skipped points (w < eps, or anything after the first
+// point of a clearing bundle) are the identity step: (M, A, D) = (1, 0, 1).
 typedef float MergeOp __attribute__((ext_vector_type(4)));  // (M, A, D, unused)
 // the table is written and read by the same wave: keep the compiler from moving LDS accesses across the hand-over
 __device__ __forceinline__ void wave_lds_handover() {
@@ -248,19 +249,24 @@ __device__ __forceinline__ void wave_lds_handover() {
 __global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba,
                                                       const u32* __restrict__ skey, const u32* __restrict__ sval, const u32* __restrict__ bstart,
                                                       RayArrays R, Counters* cnt) {
-  __shared__ MergeOp ops[4][64][8];
+  __shared__ MergeOp ops[4][64][4];
   const u32 n_bundles = uniform_u32(cnt->n_rays);
   const u32 n_valid = uniform_u32(cnt->n_valid);
   const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nthreads = gridDim.x * blockDim.x;
   const u32 lane = lane_id();
-  const u32 role = lane & 7u;  // lanes 0-6 carry a component; the others run along harmlessly on column 7
-  const bool is_pos = lane < 3;
-  MergeOp(*tbl)[8] = ops[threadIdx.x >> 6];
-  for (u32 m = uniform_u32(tid >> 6); m < n_bundles; m += nthreads >> 6) {
+  const u32 role = lane & 3u;
+  MergeOp(*tbl)[4] = ops[threadIdx.x >> 6];
+  for (u32 task = uniform_u32(tid >> 6); task < 2 * n_bundles; task += nthreads >> 6) {
+    const u32 m = task >> 1;
+    const bool colour_wave = (task & 1u) != 0;
     const u32 begin = uniform_u32(bstart[m]);
     const u32 end = uniform_u32((m + 1 < n_bundles) ? bstart[m + 1] : n_valid);
     const bool clearing = uniform_u32(skey[begin]) >= np2;
+    if (colour_wave && rgba == nullptr) {  // no colours: Color() stays (0,0,0,0)
+      if (lane == 0) R.color[m] = 0u;
+      continue;
+    }
     float val = 0.0f;  // this lane's component of the running mean / colour channel
     float W = 0.0f;    // uniform
     u64 key = 0;
@@ -276,9 +282,9 @@ __global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, co
         py = xyz[3 * idx + 1];
         pz = xyz[3 * idx + 2];
         w = voxel_weight(P, F3{px, py, pz});
-        col = pack_rgba_wire(rgba, idx);
+        if (colour_wave) col = pack_rgba_wire(rgba, idx);
       }
-      if (base == begin) {
+      if (base == begin && !colour_wave) {
         const F3 pg = transform_point(P, F3{readlane_f32(px, 0), readlane_f32(py, 0), readlane_f32(pz, 0)});
         key = pack_key(grid_index(pg.x * P.voxel_size_inv), grid_index(pg.y * P.voxel_size_inv), grid_index(pg.z * P.voxel_size_inv));
       }
@@ -297,60 +303,72 @@ __global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, co
       } else {
         float run = W;
         Wpre = W;
+        const u64 used_mask = __ballot(used);
         for (u32 k = 0; k < cnt_in; ++k) {
           if (lane == k) Wpre = run;
-          const bool uk = (__ballot(used) >> k) & 1ull;
           const float wk = readlane_f32(w, k);
-          if (uk) run += wk;
+          if ((used_mask >> k) & 1ull) run += wk;
         }
       }
       const float den = Wpre + w;
-      const float fa = Wpre / den, fb = w / den;  // colour blend factors of this point
       const float Wnext = used ? den : Wpre;
       // operand table of this chunk
       if (lane < cnt_in) {
         MergeOp* row = tbl[lane];
-        if (used) {
+        const MergeOp ident{1.0f, 0.0f, 1.0f, 0.0f};
+        if (!used) {
+#pragma unroll
+          for (u32 c = 0; c < 4; ++c) row[c] = ident;
+        } else if (!colour_wave) {
           row[0] = MergeOp{Wpre, px * w, den, 0.0f};
           row[1] = MergeOp{Wpre, py * w, den, 0.0f};
           row[2] = MergeOp{Wpre, pz * w, den, 0.0f};
-#pragma unroll
-          for (u32 c = 0; c < 4; ++c) row[3 + c] = MergeOp{fa, static_cast<float>(static_cast<int>((col >> (8u * c)) & 255u)) * fb, 1.0f, 0.0f};
-          row[7] = MergeOp{1.0f, 0.0f, 1.0f, 0.0f};
+          row[3] = ident;
         } else {
+          const float fa = Wpre / den, fb = w / den;  // colour blend factors of this point
 #pragma unroll
-          for (u32 c = 0; c < 8; ++c) row[c] = MergeOp{1.0f, 0.0f, 1.0f, 0.0f};
+          for (u32 c = 0; c < 4; ++c) row[c] = MergeOp{fa, static_cast<float>(static_cast<int>((col >> (8u * c)) & 255u)) * fb, 1.0f, 0.0f};
         }
       }
       wave_lds_handover();
       // the dependent chain
       MergeOp nxt = tbl[0][role];
-      for (u32 k = 0; k < cnt_in; ++k) {
-        const MergeOp op = nxt;
-        nxt = tbl[(k + 1) & 63u][role];  // prefetch: the operands do not depend on the chain
-        const float q = (val * op.x + op.y) / op.z;
-        val = is_pos ? q : roundf(q);
+      if (!colour_wave) {
+        for (u32 k = 0; k < cnt_in; ++k) {
+          const MergeOp op = nxt;
+          nxt = tbl[(k + 1) & 63u][role];  // prefetch: the operands do not depend on the chain
+          val = (val * op.x + op.y) / op.z;
+        }
+      } else {
+        for (u32 k = 0; k < cnt_in; ++k) {
+          const MergeOp op = nxt;
+          nxt = tbl[(k + 1) & 63u][role];
+          val = roundf(val * op.x + op.y);
+        }
       }
       wave_lds_handover();
       W = readlane_f32(Wnext, cnt_in - 1);
     }
-    const float mx = readlane_f32(val, 0), my = readlane_f32(val, 1), mz = readlane_f32(val, 2);
-    u32 mcolor = 0;
+    if (colour_wave) {
+      u32 mcolor = 0;
 #pragma unroll
-    for (u32 c = 0; c < 4; ++c) mcolor |= (static_cast<u32>(static_cast<int>(readlane_f32(val, 3 + c))) & 255u) << (8u * c);
-    if (lane == 0) {
-      const F3 pg = transform_point(P, F3{mx, my, mz});
-      Dda d;
-      dda_setup(d, P, pg, clearing);
-      if (d.range_error) atomicOr(&cnt->err, kErrRange);
-      R.px[m] = pg.x;
-      R.py[m] = pg.y;
-      R.pz[m] = pg.z;
-      R.w[m] = W;
-      R.color[m] = mcolor;
-      R.flags[m] = 1u | (clearing ? 2u : 0u);
-      R.key[m] = key;
-      R.nsteps[m] = d.nsteps;
+      for (u32 c = 0; c < 4; ++c) mcolor |= (static_cast<u32>(static_cast<int>(readlane_f32(val, c))) & 255u) << (8u * c);
+      if (lane == 0) R.color[m] = mcolor;
+    } else {
+      const float mx = readlane_f32(val, 0), my = readlane_f32(val, 1), mz = readlane_f32(val, 2);
+      if (lane == 0) {
+        const F3 pg = transform_point(P, F3{mx, my, mz});
+        Dda d;
+        dda_setup(d, P, pg, clearing);
+        if (d.range_error) atomicOr(&cnt->err, kErrRange);
+        R.px[m] = pg.x;
+        R.py[m] = pg.y;
+        R.pz[m] = pg.z;
+        R.w[m] = W;
+        R.flags[m] = 1u | (clearing ? 2u : 0u);
+        R.key[m] = key;
+        R.nsteps[m] = d.nsteps;
+      }
     }
   }
 }
@@ -1085,9 +1103,9 @@ struct cox_integrator {
   u32 hint_records = 0, hint_rays = 0;
   // timing of the apply kernels (bench roofline)
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events;
-  double apply_ms = 0.0;
-  uint64_t apply_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events, merge_events;
+  double apply_ms = 0.0, merge_ms = 0.0;
+  uint64_t apply_launches = 0, merge_launches = 0;
 };
 
 template <typename T>
@@ -1270,7 +1288,17 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     exclusive_scan_u32(I->head, I->head, nullptr, n, n, &C->n_rays, I->scanws_a, sa);
     hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, sa, n, sk, I->head, I->bstart, C);
     ray_hint = I->hint_rays ? std::min(I->hint_rays, n) : std::min<u32>(n, 16384);
-    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, sa, P, np2, xyz, rgba, sk, sv, I->bstart, R, C);
+    hipEvent_t m0 = nullptr, m1 = nullptr;
+    if (I->profiling) {
+      COX_HIP(hipEventCreate(&m0));
+      COX_HIP(hipEventCreate(&m1));
+      COX_HIP(hipEventRecord(m0, sa));
+    }
+    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 128u, 256, 8192), dim3(256), 0, sa, P, np2, xyz, rgba, sk, sv, I->bstart, R, C);
+    if (I->profiling) {
+      COX_HIP(hipEventRecord(m1, sa));
+      I->merge_events.emplace_back(m0, m1);
+    }
   } else {
     hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, sa, P, xyz, rgba, R, C);
     ray_hint = n;
@@ -1349,6 +1377,16 @@ static int integrator_finish(cox_integrator* I) {
     (void)hipEventDestroy(ev.second);
   }
   I->apply_events.clear();
+  for (auto& ev : I->merge_events) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      I->merge_ms += ms;
+      I->merge_launches += 1;
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  I->merge_events.clear();
   return err_bits_to_status(err);
 }
 
@@ -1395,10 +1433,11 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   (void)hipSetDevice(I->layer->device);
   if (I->stream_a) (void)hipStreamSynchronize(I->stream_a);
   if (I->stream) (void)hipStreamSynchronize(I->stream);
-  for (auto& ev : I->apply_events) {
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
+  for (auto* evs : {&I->apply_events, &I->merge_events})
+    for (auto& ev : *evs) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
   std::vector<void*> ptrs = {I->pslot, I->skey[0], I->skey[1], I->sval[0], I->sval[1], I->head, I->bstart, I->own_xyz, I->own_rgba, I->depth_flag,
                              I->rec_key[0], I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->piece_front, I->piece_back, I->piece_wsum, I->touched_slots,
                              I->sort_pts.counts, I->sort_pts.totals, I->sort_pts.info, I->sort_rec.counts, I->sort_rec.totals, I->sort_rec.info,
@@ -1504,6 +1543,23 @@ int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* 
   if (reset) {
     I->apply_ms = 0.0;
     I->apply_launches = 0;
+  }
+  return st;
+}
+
+
+int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launches[2], int reset) {
+  COX_ENTRY();
+  if (!I || !ms || !launches) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  int st = integrator_finish(I);
+  ms[0] = I->merge_ms;
+  launches[0] = I->merge_launches;
+  ms[1] = I->apply_ms;
+  launches[1] = I->apply_launches;
+  if (reset) {
+    I->merge_ms = I->apply_ms = 0.0;
+    I->merge_launches = I->apply_launches = 0;
   }
   return st;
 }

@@ -141,6 +141,9 @@ int cox_integrator_set_profiling(cox_integrator_t* integ, int on);
 /* HIP-event time of the dominant kernel over the calls since the last reset (bench.py roofline):
  * accumulated milliseconds and launch count of the TSDF update ("apply") stage */
 int cox_integrator_kernel_time(cox_integrator_t* integ, double* apply_ms, uint64_t* apply_launches, int reset);
+/* same for two kernels at once: [0] = k_bundle_merge (merged integrator's ray generation, the longest kernel of a
+ * frame), [1] = the TSDF update stage (k_apply_eval + k_apply_long) */
+int cox_integrator_stage_times(cox_integrator_t* integ, double ms[2], uint64_t launches[2], int reset);
 
 /* ---- registration (voxgraph RegistrationCostFunction) ------------------------------------- */
 typedef struct cox_reg_config {
