@@ -1,0 +1,209 @@
+// C++ adapters that give the C ABI of include/coxgraph_hip.h the signatures coxgraph's host code already
+// uses (voxblox / voxgraph shapes), so a call site such as
+//     tsdf_integrator_->integratePointCloud(T_G_C, *points_C, *colors, false);      // tsdf_recover.h:75
+// keeps its form.  Header-only, dependency-free C++14 (the reference builds with -std=c++14,
+// coxgraph/CMakeLists.txt:4); link with -lcoxgraph_hip.  Failures throw std::runtime_error where the reference
+// would glog-CHECK-abort.  See INTEGRATION.md for the glue to the real voxblox / Eigen / ROS types.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/coxgraph_hip.h"
+
+namespace coxgraph_hip {
+
+inline void check(int status, const char* what) {
+  if (status != COX_OK) throw std::runtime_error(std::string(what) + ": " + cox_status_string(status));
+}
+
+// voxblox::Transformation (kindr::minimal::QuatTransformationTemplate<float>): rotation (w,x,y,z) + position
+struct Transformation {
+  float q[4] = {1.f, 0.f, 0.f, 0.f};
+  float t[3] = {0.f, 0.f, 0.f};
+  void pack(float out[7]) const {
+    for (int i = 0; i < 4; ++i) out[i] = q[i];
+    for (int i = 0; i < 3; ++i) out[4 + i] = t[i];
+  }
+};
+using Point = std::array<float, 3>;  // voxblox::Point (Eigen::Vector3f), tightly packed
+struct Color {                       // voxblox::Color
+  uint8_t r = 0, g = 0, b = 0, a = 0;
+};
+using Pointcloud = std::vector<Point>;  // voxblox::Pointcloud
+using Colors = std::vector<Color>;      // voxblox::Colors
+static_assert(sizeof(Point) == 12 && sizeof(Color) == 4, "packed layouts expected by the C ABI");
+
+// voxblox_msgs/Layer (the part coxgraph touches: utils/msg_converter.h:149-167)
+struct BlockMsg {
+  int32_t x_index, y_index, z_index;
+  std::vector<uint32_t> data;  // 3 words per voxel, 4096 voxels
+};
+struct LayerMsg {
+  double voxel_size = 0.0;
+  uint32_t voxels_per_side = 16;
+  std::string layer_type = "tsdf";
+  uint8_t action = 0;  // 0 update, 1 merge, 2 reset
+  std::vector<BlockMsg> blocks;
+};
+
+// voxblox::Layer<TsdfVoxel>
+class TsdfLayer {
+ public:
+  TsdfLayer(float voxel_size, size_t voxels_per_side = 16, int device = 0, uint64_t capacity_blocks = 0) : voxel_size_(voxel_size), vps_(voxels_per_side) {
+    check(cox_layer_create(voxel_size, static_cast<int>(voxels_per_side), device, capacity_blocks, &h_), "Layer");
+  }
+  ~TsdfLayer() { cox_layer_destroy(h_); }
+  TsdfLayer(const TsdfLayer&) = delete;
+  TsdfLayer& operator=(const TsdfLayer&) = delete;
+
+  void removeAllBlocks() { check(cox_layer_clear(h_), "removeAllBlocks"); }  // tsdf_recover.h:62
+  size_t getNumberOfAllocatedBlocks() const {                                // map_server.h:142
+    uint64_t n = 0;
+    check(cox_layer_stats(h_, &n, nullptr), "getNumberOfAllocatedBlocks");
+    return n;
+  }
+  size_t getMemorySize() const {  // tsdf_recover.h:92
+    uint64_t b = 0;
+    check(cox_layer_stats(h_, nullptr, &b), "getMemorySize");
+    return b;
+  }
+  float voxel_size() const { return voxel_size_; }
+  size_t voxels_per_side() const { return vps_; }
+  float block_size() const { return voxel_size_ * static_cast<float>(vps_); }  // map_server.cpp:124
+  cox_layer_t* handle() const { return h_; }
+
+ private:
+  cox_layer_t* h_ = nullptr;
+  float voxel_size_;
+  size_t vps_;
+};
+
+// voxblox::serializeLayerAsMsg<TsdfVoxel>(layer, only_updated = false, &msg)   (utils/msg_converter.h:49)
+inline void serializeLayerAsMsg(const TsdfLayer& layer, bool /*only_updated*/, LayerMsg* msg) {
+  uint64_t n = 0;
+  check(cox_layer_download(layer.handle(), nullptr, nullptr, 0, &n), "serializeLayerAsMsg");
+  std::vector<int32_t> idx(3 * n);
+  std::vector<uint32_t> words(n * 4096 * 3);
+  if (n) check(cox_layer_download(layer.handle(), idx.data(), words.data(), n, &n), "serializeLayerAsMsg");
+  msg->voxel_size = layer.voxel_size();
+  msg->voxels_per_side = static_cast<uint32_t>(layer.voxels_per_side());
+  msg->layer_type = "tsdf";
+  msg->action = 0;
+  msg->blocks.resize(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    BlockMsg& b = msg->blocks[i];
+    b.x_index = idx[3 * i];
+    b.y_index = idx[3 * i + 1];
+    b.z_index = idx[3 * i + 2];
+    b.data.assign(words.begin() + i * 12288, words.begin() + (i + 1) * 12288);
+  }
+}
+// voxblox::deserializeMsgToLayer(msg, layer) -> bool   (utils/msg_converter.h:107)
+inline bool deserializeMsgToLayer(const LayerMsg& msg, TsdfLayer* layer) {
+  if (msg.layer_type != "tsdf" || msg.voxels_per_side != layer->voxels_per_side() ||
+      static_cast<float>(msg.voxel_size) != layer->voxel_size())
+    return false;
+  const uint64_t n = msg.blocks.size();
+  std::vector<int32_t> idx(3 * n);
+  std::vector<uint32_t> words(n * 12288);
+  for (uint64_t i = 0; i < n; ++i) {
+    const BlockMsg& b = msg.blocks[i];
+    if (b.data.size() != 12288) return false;
+    idx[3 * i] = b.x_index;
+    idx[3 * i + 1] = b.y_index;
+    idx[3 * i + 2] = b.z_index;
+    std::copy(b.data.begin(), b.data.end(), words.begin() + i * 12288);
+  }
+  return cox_layer_upload(layer->handle(), idx.data(), words.data(), n, msg.action) == COX_OK;
+}
+
+// voxblox::TsdfIntegratorBase::Config
+struct TsdfIntegratorConfig : cox_tsdf_config {
+  TsdfIntegratorConfig() { cox_tsdf_config_default(this); }
+};
+
+// voxblox::TsdfIntegratorBase + TsdfIntegratorFactory
+class TsdfIntegrator {
+ public:
+  using Ptr = std::shared_ptr<TsdfIntegrator>;
+  // TsdfIntegratorFactory::create(method, config, layer): method in {"simple", "merged", "fast"}
+  static Ptr create(const std::string& method, const TsdfIntegratorConfig& config, TsdfLayer* layer) {
+    int m = -1;
+    if (method == "simple") m = COX_METHOD_SIMPLE;
+    if (method == "merged") m = COX_METHOD_MERGED;
+    if (method == "fast") m = COX_METHOD_FAST;
+    if (m < 0) throw std::runtime_error("Unknown TSDF integrator type: " + method);
+    return Ptr(new TsdfIntegrator(m, config, layer));
+  }
+  ~TsdfIntegrator() { cox_integrator_destroy(h_); }
+  // TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace_points)
+  void integratePointCloud(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors, const bool freespace_points = false) {
+    if (!colors.empty() && colors.size() != points_C.size()) throw std::runtime_error("integratePointCloud: points_C.size() != colors.size()");
+    float T[7];
+    T_G_C.pack(T);
+    check(cox_integrate_points(h_, T, points_C.empty() ? nullptr : points_C[0].data(), colors.empty() ? nullptr : &colors[0].r, points_C.size(),
+                               freespace_points ? 1 : 0),
+          "integratePointCloud");
+  }
+  cox_frame_stats lastFrameStats() const {
+    cox_frame_stats s;
+    check(cox_integrator_last_stats(h_, &s), "lastFrameStats");
+    return s;
+  }
+  cox_integrator_t* handle() const { return h_; }
+
+ private:
+  TsdfIntegrator(int method, const TsdfIntegratorConfig& config, TsdfLayer* layer) { check(cox_integrator_create(layer->handle(), &config, method, &h_), "TsdfIntegrator"); }
+  cox_integrator_t* h_ = nullptr;
+};
+
+// voxgraph::RegistrationPoint
+struct RegistrationPoint {
+  float position[3];
+  float distance;
+  float weight;
+};
+static_assert(sizeof(RegistrationPoint) == 20, "5 packed floats expected by the C ABI");
+
+// voxgraph::RegistrationCostFunction for one (reference submap, reading submap) pair.  Derive from
+// ceres::CostFunction in a Ceres build; Evaluate has exactly the Ceres signature.
+class RegistrationCostFunction {
+ public:
+  RegistrationCostFunction(const std::vector<RegistrationPoint>& reference_points, const TsdfLayer& reading_layer, double no_correspondence_cost = 0.0,
+                           int device = 0)
+      : n_(reference_points.size()) {
+    check(cox_regpoints_create(device, reference_points.empty() ? nullptr : reference_points[0].position, n_, &pts_), "RegistrationCostFunction");
+    cox_reg_config cfg{no_correspondence_cost};
+    check(cox_reg_create(pts_, reading_layer.handle(), &cfg, &reg_), "RegistrationCostFunction");
+  }
+  ~RegistrationCostFunction() {
+    cox_reg_destroy(reg_);
+    cox_regpoints_destroy(pts_);
+  }
+  int num_residuals() const { return static_cast<int>(sample_idx_.empty() ? n_ : sample_idx_.size()); }
+  // the weighted sampler's draws (sampling_ratio > 0); empty = every point once (sampling_ratio = -1)
+  void setSampleIndices(const std::vector<uint32_t>& idx) { sample_idx_ = idx; }
+  // ceres::CostFunction::Evaluate: parameters = {reference pose (x,y,z,yaw), reading pose}, jacobians row-major N x 4
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+    const uint32_t* si = sample_idx_.empty() ? nullptr : sample_idx_.data();
+    return cox_reg_evaluate(reg_, parameters[0], parameters[1], si, num_residuals(), residuals, jacobians ? jacobians[0] : nullptr,
+                            jacobians ? jacobians[1] : nullptr) == COX_OK;
+  }
+  // fused Gauss-Newton block: H = J^T J (8x8), b = J^T r, cost = |r|^2 / 2
+  bool NormalEquations(const double ref[4], const double read[4], double H[64], double b[8], double* cost) const {
+    const uint32_t* si = sample_idx_.empty() ? nullptr : sample_idx_.data();
+    return cox_reg_normal_eq(reg_, ref, read, si, num_residuals(), H, b, cost, nullptr) == COX_OK;
+  }
+
+ private:
+  size_t n_;
+  cox_regpoints_t* pts_ = nullptr;
+  cox_reg_t* reg_ = nullptr;
+  std::vector<uint32_t> sample_idx_;
+};
+
+}  // namespace coxgraph_hip

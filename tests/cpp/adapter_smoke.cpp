@@ -1,0 +1,63 @@
+// Mirrors the only in-tree caller of the integrator, TsdfRecover::processMesh
+// (coxgraph/include/coxgraph/map_comm/tsdf_recover.h:59-99): clear the layer, integrate a few point
+// clouds, report the layer memory, serialise it -- through the C++ adapters.  Exit code 0 = all good;
+// 77 = no GPU (the constructors fail with COX_ERR_NO_DEVICE, nothing falls back).
+#include <cmath>
+#include <cstdio>
+
+#include "../../coxgraph_amd/host/coxgraph_hip_adapters.hpp"
+
+using namespace coxgraph_hip;
+
+int main() {
+  if (cox_device_count() == 0) {
+    try {
+      TsdfLayer layer(0.10f);
+    } catch (const std::runtime_error& e) {
+      std::printf("no GPU: %s\n", e.what());
+      return 77;
+    }
+    return 1;
+  }
+  TsdfLayer layer(0.10f, 16, 0, 2048);
+  TsdfIntegratorConfig cfg;
+  cfg.default_truncation_distance = 0.3f;
+  cfg.use_const_weight = 1;
+  cfg.max_ray_length_m = 10.0f;
+  cfg.min_ray_length_m = 0.2f;
+  auto integrator = TsdfIntegrator::create("merged", cfg, &layer);
+  layer.removeAllBlocks();
+  Pointcloud points_C;
+  Colors colors;
+  for (int v = 0; v < 60; ++v)
+    for (int u = 0; u < 80; ++u) {  // a wall 2 m in front of the camera
+      points_C.push_back({{2.0f * (u - 40) / 60.0f, 2.0f * (v - 30) / 60.0f, 2.0f}});
+      colors.push_back(Color{static_cast<uint8_t>(u), static_cast<uint8_t>(v), 128, 255});
+    }
+  Transformation T_G_C;
+  for (int i = 0; i < 3; ++i) {
+    T_G_C.t[0] = 0.05f * i;
+    integrator->integratePointCloud(T_G_C, points_C, colors, false);
+  }
+  const cox_frame_stats st = integrator->lastFrameStats();
+  std::printf("layer memory: %zu bytes, %zu blocks; last frame: %llu rays, %llu updates\n", layer.getMemorySize(), layer.getNumberOfAllocatedBlocks(),
+              (unsigned long long)st.n_rays, (unsigned long long)st.n_updates);
+  LayerMsg msg;
+  serializeLayerAsMsg(layer, false, &msg);
+  if (msg.blocks.empty() || msg.blocks.size() != layer.getNumberOfAllocatedBlocks()) return 2;
+  TsdfLayer copy(0.10f, 16, 0, 2048);
+  if (!deserializeMsgToLayer(msg, &copy) || copy.getMemorySize() != layer.getMemorySize()) return 3;
+  // registration of the wall against itself: zero residuals at identical poses
+  std::vector<RegistrationPoint> pts;
+  for (int i = 0; i < 500; ++i) pts.push_back(RegistrationPoint{{0.01f * (i % 50), 0.02f * (i / 50), 2.0f}, 0.0f, 1.0f});
+  RegistrationCostFunction cost(pts, layer);
+  std::vector<double> r(pts.size()), jf(4 * pts.size()), jr(4 * pts.size());
+  const double pose[4] = {0, 0, 0, 0};
+  const double* params[2] = {pose, pose};
+  double* jac[2] = {jf.data(), jr.data()};
+  if (!cost.Evaluate(params, r.data(), jac)) return 4;
+  double worst = 0;
+  for (double x : r) worst = std::fmax(worst, std::fabs(x));
+  std::printf("registration max |r| = %g\n", worst);
+  return worst < 0.06 ? 0 : 5;
+}

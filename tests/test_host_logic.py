@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: pose-graph costs/solver (driving the ORACLE registration cost as the
+evaluator -- tests only), C++ adapters compile and link against the C ABI, bench.py's CPU-side pieces."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from coxgraph_amd.capi import Layer, RegPoints, Registration
+from coxgraph_amd.posegraph import PoseGraph, PoseGraphInterface, RelativePoseConstraint, normalize_angle, sqrt_information
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_normalize_angle_and_sqrt_information():
+    assert abs(normalize_angle(3.5 * np.pi) - (-0.5 * np.pi)) < 1e-12
+    assert abs(normalize_angle(-np.pi) - (-np.pi)) < 1e-12 and abs(normalize_angle(np.pi) - (-np.pi)) < 1e-12
+    info = np.diag([100.0, 100.0, 250.0, 250.0])  # coxgraph/config/server.yaml:37-43
+    L = sqrt_information(info)
+    assert np.allclose(L.T @ L, info)
+    semi = np.diag([1.0, 0.0, 4.0, 9.0])
+    L = sqrt_information(semi)
+    assert np.allclose(L.T @ L, semi)
+
+
+def test_relative_pose_cost_known_answers_and_jacobian():
+    """Appendix D.8: A = (0,0,0,0), B = (1,0,0,pi/2), obs = same -> r = 0; yaw wraps at +-pi."""
+    c = RelativePoseConstraint(0, 1, [1, 0, 0, np.pi / 2], np.eye(4))
+    r, Ja, Jb = c.evaluate(np.zeros(4), np.array([1.0, 0, 0, np.pi / 2]))
+    assert np.allclose(r, 0)
+    c2 = RelativePoseConstraint(0, 1, [0, 0, 0, np.pi - 0.01], np.eye(4))
+    r, _, _ = c2.evaluate(np.zeros(4), np.array([0, 0, 0, -np.pi + 0.01]))
+    assert abs(r[3] - 0.02) < 1e-12  # shortest way round, not 2*pi - 0.02
+    rng = np.random.default_rng(0)
+    c3 = RelativePoseConstraint(0, 1, rng.normal(size=4), np.diag([100.0, 100.0, 250.0, 250.0]))
+    pa, pb = rng.normal(size=4), rng.normal(size=4)
+    r0, Ja, Jb = c3.evaluate(pa, pb)
+    h = 1e-6
+    for k in range(4):
+        e = np.zeros(4)
+        e[k] = h
+        assert np.allclose((c3.evaluate(pa + e, pb)[0] - c3.evaluate(pa - e, pb)[0]) / (2 * h), Ja[:, k], atol=1e-5)
+        assert np.allclose((c3.evaluate(pa, pb + e)[0] - c3.evaluate(pa, pb - e)[0]) / (2 * h), Jb[:, k], atol=1e-5)
+
+
+def test_loop_closure_chain_optimises_to_consistent_poses():
+    g = PoseGraphInterface()
+    truth = {0: np.array([0.0, 0, 0, 0]), 1: np.array([1.0, 0.5, 0.1, 0.3]), 2: np.array([2.0, -0.5, 0.2, -0.2])}
+    rng = np.random.default_rng(1)
+    for k, p in truth.items():
+        g.addSubmap(k, p + (0 if k == 0 else rng.normal(scale=0.2, size=4)))
+
+    def rel(a, b):
+        c, s = np.cos(truth[a][3]), np.sin(truth[a][3])
+        d = truth[b][:3] - truth[a][:3]
+        return [c * d[0] + s * d[1], -s * d[0] + c * d[1], d[2], truth[b][3] - truth[a][3]]
+
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        g.addLoopClosureMeasurement(a, b, rel(a, b))
+    first, second = g.optimize(enable_registration=False)
+    poses = g.getPoseMap()
+    for k in truth:
+        assert np.allclose(poses[k], truth[k], atol=1e-6), (k, poses[k])
+    assert np.array_equal(poses[0], truth[0])  # submap 0 is constant (pose_graph_interface.cpp:20-25)
+    assert second["final_cost"] < 1e-12
+
+
+def plane_layer(eng, voxel=0.1, a=-1.0, b=(1.0, 0.0, 0.0), blocks=None):
+    blocks = blocks or [(x, y, z) for x in range(-1, 3) for y in range(-1, 3) for z in range(-1, 2)]
+    idx = np.array(blocks, np.int32)
+    vox = np.zeros((len(blocks), 4096, 3), np.uint32)
+    lin = np.arange(4096)
+    loc = np.stack([lin % 16, (lin // 16) % 16, lin // 256], axis=1)
+    for i, blk in enumerate(blocks):
+        c = (np.array(blk)[None, :] * 16 + loc + 0.5) * voxel
+        vox[i, :, 0] = (a + c @ np.array(b)).astype(np.float32).view(np.uint32)
+        vox[i, :, 1] = np.float32(2.0).view(np.uint32)
+    layer = Layer(eng, voxel)
+    layer.upload(idx, vox)
+    return layer
+
+
+def corner_problem(eng):
+    """Reading submap = three orthogonal planes x=1, y=0.8, z=0.5 meeting in a corner is not expressible as one linear
+    field, so use a smooth quadratic-free surrogate: distance to the plane x + 0.5 y + 0.25 z = 1.2 (normalised); yaw and all
+    three translations are observable from points spread in space only along the normal, so anchor the rest by loop closure."""
+    n = np.array([1.0, 0.5, 0.25])
+    n /= np.linalg.norm(n)
+    layer = plane_layer(eng, a=-1.2 / np.linalg.norm([1.0, 0.5, 0.25]), b=tuple(n))
+    rng = np.random.default_rng(4)
+    xyz = rng.uniform([0.0, 0.0, 0.0], [2.0, 2.0, 1.0], (400, 3))
+    d = xyz @ n - 1.2 / np.linalg.norm([1.0, 0.5, 0.25])
+    keep = np.abs(d) < 0.25
+    pts = np.concatenate([xyz[keep], d[keep, None], rng.uniform(0.5, 2.0, (keep.sum(), 1))], axis=1).astype(np.float32)
+    return layer, pts, n
+
+
+def test_registration_constraint_pulls_pose_onto_the_surface(oracle):
+    layer, pts, n = corner_problem(oracle)
+    reg = Registration(oracle, RegPoints(oracle, pts), layer)
+    g = PoseGraphInterface()
+    g.addSubmap(0, [0, 0, 0, 0])
+    off = 0.08 * n  # reading submap displaced along the surface normal: the registration cost sees exactly this
+    g.addSubmap(1, [off[0], off[1], off[2], 0.0])
+    g.addForceRegistrationConstraint(0, 1, reg)
+    # weak prior keeps the unobservable directions where they are
+    g.pose_graph.rel.append(RelativePoseConstraint(0, 1, [off[0], off[1], off[2], 0.0], np.eye(4) * 1e-3))
+    before = reg.normal_eq(np.zeros(4), g.getPoseMap()[1])[2]
+    g.optimize(enable_registration=True)
+    p1 = g.getPoseMap()[1]
+    after = reg.normal_eq(np.zeros(4), p1)[2]
+    assert before > 1e-3 and after < 1e-6 * max(1.0, before)
+    assert abs(float(p1[:3] @ n)) < 2e-3  # the displacement along the normal is gone
+
+
+def test_cpp_adapters_compile_and_link_against_the_c_abi(hip, tmp_path):
+    """The reference-shaped C++ wrappers (coxgraph_amd/host) build with -std=c++14 like the reference
+    (coxgraph/CMakeLists.txt:4) and link against the shared library; without a GPU the program reports so."""
+    exe = str(tmp_path / "adapter_smoke")
+    libdir = os.path.dirname(hip.path)
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"),
+                           "-L" + libdir, "-lcoxgraph_hip", "-Wl,-rpath," + libdir])
+    rc = subprocess.call([exe])
+    assert rc == (0 if hip.device_count() > 0 else 77)
+
+
+@pytest.mark.gpu
+def test_cpp_adapters_run_on_the_gpu(hip, tmp_path):
+    exe = str(tmp_path / "adapter_smoke")
+    libdir = os.path.dirname(hip.path)
+    subprocess.check_call(["g++", "-std=c++14", "-o", exe, os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"), "-L" + libdir, "-lcoxgraph_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
