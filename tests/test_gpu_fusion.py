@@ -216,3 +216,21 @@ def test_results_are_reproducible_run_to_run(hip):
     ia, va = a.download()
     ib, vb = b.download()
     assert np.array_equal(ia, ib) and np.array_equal(va, vb)
+
+
+def test_config4_shape_1280x720_2cm(hip, oracle):
+    """BASELINE configs[3] input shape: 1280x720 depth (921 600 points), 2 cm voxels, rays 0.1-3 m (tsdf_server_rs.yaml:12-17)."""
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.02, frames=[0, 30], capacity_blocks=65536, wh=(1280, 720))
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(rep, sa[-1])
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0
+
+
+def test_one_centimetre_voxels(hip, oracle):
+    """BASELINE configs[4] voxel size (extrapolated ray limits): thousands of blocks, ~1e6 voxels per frame."""
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.01, frames=[0], subsample=2, capacity_blocks=131072)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(rep, sa[-1])
+    assert rep["bitexact_d"] and rep["bitexact_w"]
