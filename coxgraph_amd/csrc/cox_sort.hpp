@@ -134,7 +134,7 @@ struct SortInfo {
 
 template <int RB>
 __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ k0, const u32* __restrict__ k1, const u32* __restrict__ d_n, u32 n_max,
-                                                        int pass, const SortInfo* __restrict__ info, int host_bits, u32* __restrict__ counts /*[2^RB][n_tiles_cap]*/,
+                                                        int pass, const SortInfo* __restrict__ info, int host_bits, u32* __restrict__ counts /*[n_tiles][2^RB]*/,
                                                         u32 tiles_cap, u32* __restrict__ totals /*[2^RB]*/) {
   constexpr u32 kDigits = 1u << RB;
   __shared__ u32 h[kDigits];
@@ -151,41 +151,57 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ 
     __syncthreads();
     for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) {
       const u32 c = h[d];
-      counts[static_cast<size_t>(d) * tiles_cap + tile] = c;
+      counts[static_cast<size_t>(tile) * kDigits + d] = c;  // tile-major: coalesced here and in the scatter kernel
       if (c) atomicAdd(&totals[d], c);
     }
     __syncthreads();
   }
 }
 
-// one block per digit: counts[d][0..n_tiles) -> exclusive prefix over tiles + sum of the totals of all lower digits
+// counts[tile][digit] -> position of the first element of (tile, digit) in the sorted output =
+// (sum of the totals of all lower digits) + (counts of the same digit in all lower tiles).
+// One workgroup owns 64 digits (lane = digit, so every access is a coalesced 256-B row segment); its 16 waves
+// split the tiles: partial sums, a prefix over the waves, then the running prefix is written back.
+constexpr int kRsOffThreads = 1024;
 template <int RB>
-__global__ void __launch_bounds__(kRsThreads) k_rs_offsets(const u32* __restrict__ d_n, u32 n_max, int pass, SortInfo* __restrict__ info, int host_bits,
-                                                           u32* __restrict__ counts, u32 tiles_cap, const u32* __restrict__ totals) {
+__global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restrict__ d_n, u32 n_max, int pass, SortInfo* __restrict__ info, int host_bits,
+                                                              u32* __restrict__ counts, u32 tiles_cap, const u32* __restrict__ totals) {
   constexpr u32 kDigits = 1u << RB;
-  __shared__ u32 lds[4];
+  constexpr u32 kWaves = kRsOffThreads / 64;
+  __shared__ u32 lds[16];
+  __shared__ u32 part[kWaves][64];
+  __shared__ u32 group_base;
   const int shift = pass * RB;
   if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
-  for (u32 d = blockIdx.x; d < kDigits; d += gridDim.x) {
-    // base = sum of totals[0..d)
-    u32 part = 0;
-    for (u32 j = threadIdx.x; j < d; j += kRsThreads) part += totals[j];
-    u32 base;
-    (void)block_exclusive_scan<4>(part, &base, lds);
-    u32* row = counts + static_cast<size_t>(d) * tiles_cap;
-    u32 carry = base;
-    for (u32 t0 = 0; t0 < n_tiles; t0 += kRsThreads) {
-      const u32 t = t0 + threadIdx.x;
-      const u32 v = (t < n_tiles) ? row[t] : 0u;
-      u32 total;
-      const u32 ex = block_exclusive_scan<4>(v, &total, lds);
-      if (t < n_tiles) row[t] = carry + ex;
-      carry += total;
-    }
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 d0 = blockIdx.x * 64u;  // first digit of this group
+  // sum of the totals of all digits below the group
+  u32 below = 0;
+  for (u32 j = threadIdx.x; j < d0; j += kRsOffThreads) below += totals[j];
+  u32 tot;
+  (void)block_exclusive_scan<kWaves>(below, &tot, lds);
+  if (threadIdx.x == 0) group_base = tot;
+  // exclusive prefix of the group's own totals (wave 0)
+  const u32 my_total = totals[d0 + lane];
+  const u32 digit_excl = wave_inclusive_scan(my_total) - my_total;
+  // partial sums of this wave's tile range
+  const u32 chunk = (n_tiles + kWaves - 1) / kWaves;
+  const u32 t_begin = min(n_tiles, wave * chunk), t_end = min(n_tiles, t_begin + chunk);
+  u32 sum = 0;
+  for (u32 t = t_begin; t < t_end; ++t) sum += counts[static_cast<size_t>(t) * kDigits + d0 + lane];
+  part[wave][lane] = sum;
+  __syncthreads();
+  u32 run = group_base + digit_excl;
+  for (u32 w = 0; w < wave; ++w) run += part[w][lane];
+  for (u32 t = t_begin; t < t_end; ++t) {
+    u32* p = counts + static_cast<size_t>(t) * kDigits + d0 + lane;
+    const u32 v = *p;
+    *p = run;
+    run += v;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) info->parity = (pass + 1) & 1;  // this pass will run: its output buffer is current
+  if (blockIdx.x == 0 && threadIdx.x == 0) info->parity = (pass + 1) & 1;  // this pass runs: its output buffer is current
 }
 
 // wave-wide "which lanes hold my digit" (RB ballots), restricted to lanes with valid == true
@@ -230,7 +246,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
     __syncthreads();
     // counts -> output positions: global position of (tile, digit) + counts of the lower waves
     for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) {
-      u32 run = offsets[static_cast<size_t>(d) * tiles_cap + tile];
+      u32 run = offsets[static_cast<size_t>(tile) * kDigits + d];
 #pragma unroll
       for (u32 w = 0; w < kRsWaves; ++w) {
         const u32 c = base[w][d];
@@ -266,7 +282,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
 }
 
 struct SortWorkspace {
-  u32* counts = nullptr;   // [2^11][tiles_cap]
+  u32* counts = nullptr;   // [tiles_cap][2^11]
   u32 tiles_cap = 0;       // >= ceil(capacity / kRsTile)
   u32* totals = nullptr;   // [kRsMaxPasses][2^11], zeroed by the sort
   SortInfo* info = nullptr;  // device
@@ -290,7 +306,7 @@ static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32
   for (int p = 0; p < passes; ++p) {
     u32* totals = ws.totals + static_cast<size_t>(p) * (1u << 11);
     hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
-    hipLaunchKernelGGL(k_rs_offsets<RB>, dim3(1u << RB), dim3(kRsThreads), 0, s, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_offsets<RB>, dim3((1u << RB) / 64u), dim3(kRsOffThreads), 0, s, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
     hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap);
   }
   return bits_on_device ? -1 : (passes & 1);
