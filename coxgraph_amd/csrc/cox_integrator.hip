@@ -1061,47 +1061,66 @@ __global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ 
 // =================================================================================================
 // host side
 // =================================================================================================
+// A frame is four pipeline stages, each on its own HIP stream, so that up to four frames are in flight:
+//   A1  bundle hash + bundling sort           (input only)            stream[0]
+//   A2  bundle boundaries + sequential means  (-> ray arrays)         stream[1]
+//   B1  record offsets, touch, emit, sort     (allocates blocks)      stream[2]
+//   B2  apply                                 (writes voxels)         stream[3]
+// (simple integrator: A1 is empty, A2 is k_rays_simple.)  B1 of frame t+1 beside B2 of frame t is safe: B1 only
+// inserts new hash entries / bumps the pool and restamps ordinals that B2 never reads (it goes through its own
+// frame's touched_slots), B2 only writes voxels.  Buffers are replicated by lifetime: what lives from A1 to B2
+// (counters, ray arrays, bundle hash) x4, A1->A2 (bundling sort buffers) x2, B1->B2 (records, touched blocks,
+// piece summaries, sort info) x2.  Events order producer -> consumer and consumer -> next writer of the same copy.
 constexpr int kStatRing = 8;
+constexpr int kFrameSets = 4;
+
+struct FrameSet {  // lives A1 .. B2
+  Counters* cnt = nullptr;
+  RayArrays rays{};
+  u64* fh_keys = nullptr;  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
+  u32* fh_first = nullptr;
+  hipEvent_t done = nullptr;  // B2 of the frame that used this set
+  bool used = false;
+};
+struct BundleSet {  // lives A1 .. A2
+  u32 *pslot = nullptr, *skey[2] = {nullptr, nullptr}, *sval[2] = {nullptr, nullptr}, *head = nullptr, *bstart = nullptr;
+  hipEvent_t done = nullptr;  // A2 of the frame that used this set
+  bool used = false;
+};
+struct RecordSet {  // lives B1 .. B2
+  u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
+  u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
+  u32* touched_slots = nullptr;  // [layer ht_cap]
+  SortInfo* sort_info = nullptr;
+  hipEvent_t done = nullptr;  // B2 of the frame that used this set
+  bool used = false;
+};
 
 struct cox_integrator {
   cox_layer* layer = nullptr;
   cox_tsdf_config cfg;
   int method = 0;
-  // Two streams form a two-stage pipeline across frames: stage A (ray generation: depends only on the frame's
-  // input) of frame t+1 runs beside stage B (layer update) of frame t.  Everything stage A hands to stage B is
-  // double-buffered (index = frame number & 1).
-  hipStream_t stream = nullptr;   // stage B, also the stream the host API copies on
-  hipStream_t stream_a = nullptr; // stage A
-  hipEvent_t ev_a_done[2] = {nullptr, nullptr}, ev_b_done[2] = {nullptr, nullptr};
-  bool b_used[2] = {false, false};
-  // point-sized workspace
-  u32 pcap = 0;
-  RayArrays rays2[2] = {};
-  u32 *pslot = nullptr, *skey[2] = {nullptr, nullptr}, *sval[2] = {nullptr, nullptr}, *head = nullptr, *bstart = nullptr;
-  u64* fh_keys2[2] = {nullptr, nullptr};  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
-  u32* fh_first2[2] = {nullptr, nullptr};
-  u32 fh_cap = 0;
+  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // A1, A2, B1, B2
+  hipEvent_t ev_a1 = nullptr, ev_a2 = nullptr, ev_b1 = nullptr;  // per-frame hand-over events (re-recorded every frame)
+  FrameSet fs[kFrameSets];
+  BundleSet bs[2];
+  RecordSet rs[2];
+  u32 pcap = 0, rcap = 0, fh_cap = 0;
+  u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
   float* own_xyz = nullptr;  // staging for host / depth inputs
   uint8_t* own_rgba = nullptr;
   u32* depth_flag = nullptr;
-  // record-sized workspace
-  u32 rcap = 0;
-  u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
-  u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
-  u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
-  u32* touched_slots = nullptr;  // [layer ht_cap]
+  u32* d_depth_n = nullptr;  // point count of the depth front end
   SortWorkspace sort_pts, sort_rec;
-  ScanWorkspace scanws_a, scanws_b;
+  ScanWorkspace scanws_a, scanws_b, scanws_d;
   u32 scan_cap = 0;
-  Counters* d_cnt2 = nullptr;  // two frames in flight
-  u32* d_depth_n = nullptr;    // point count of the depth front end
   Counters* h_ring = nullptr;  // pinned, kStatRing entries
   uint64_t frame_no = 0;       // frames enqueued
   uint64_t counts_frame = 0;   // frame whose end-of-frame counters were last enqueued (0 = none)
   cox_frame_stats last{};      // host-known part of the last frame's stats
   bool last_has_counts = false;
   u32 hint_records = 0, hint_rays = 0;
-  // timing of the apply kernels (bench roofline)
+  // timing of individual kernels (bench roofline)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events, merge_events;
   double apply_ms = 0.0, merge_ms = 0.0;
@@ -1130,10 +1149,6 @@ static int alloc_sort_ws(SortWorkspace* ws, u64 capacity) {
   ws->tiles_cap = std::max<u32>(1, sort_num_tiles(capacity));
   COX_TRY(dev_realloc(&ws->counts, static_cast<size_t>(ws->tiles_cap) * (1u << 11)));
   if (!ws->totals) COX_TRY(dev_realloc(&ws->totals, static_cast<size_t>(kRsMaxPasses) * (1u << 11)));
-  if (!ws->info) {
-    COX_TRY(dev_realloc(&ws->info, 1));
-    COX_HIP(hipMemset(ws->info, 0, sizeof(SortInfo)));
-  }
   return COX_OK;
 }
 
@@ -1145,13 +1160,19 @@ static u32 max_steps_per_ray(const cox_integrator* I) {
   return static_cast<u32>(std::min(s, 1.0e6));
 }
 
+static int sync_all(cox_integrator* I) {
+  for (int k = 0; k < 4; ++k)
+    if (I->st[k]) COX_HIP(hipStreamSynchronize(I->st[k]));
+  return COX_OK;
+}
+
 static int ensure_capacity(cox_integrator* I, u32 n) {
   if (n <= I->pcap) return COX_OK;
-  COX_HIP(hipStreamSynchronize(I->stream_a));
-  COX_HIP(hipStreamSynchronize(I->stream));
+  COX_TRY(sync_all(I));
   const u32 cap = std::max<u32>(n, 1024);
-  for (int b = 0; b < 2; ++b) {
-    RayArrays& R = I->rays2[b];
+  I->fh_cap = next_pow2(static_cast<u64>(cap) + cap / 2);  // load factor <= 2/3 even if every point is its own bundle
+  for (FrameSet& F : I->fs) {
+    RayArrays& R = F.rays;
     COX_TRY(dev_realloc(&R.px, cap));
     COX_TRY(dev_realloc(&R.py, cap));
     COX_TRY(dev_realloc(&R.pz, cap));
@@ -1161,22 +1182,21 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&R.key, cap));
     COX_TRY(dev_realloc(&R.nsteps, cap));
     COX_TRY(dev_realloc(&R.rec_off, cap));
+    COX_TRY(dev_realloc(&F.fh_keys, static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
+    F.fh_first = reinterpret_cast<u32*>(F.fh_keys + I->fh_cap);
   }
-  COX_TRY(dev_realloc(&I->pslot, cap));
-  for (int k = 0; k < 2; ++k) {
-    COX_TRY(dev_realloc(&I->skey[k], cap));
-    COX_TRY(dev_realloc(&I->sval[k], cap));
+  for (BundleSet& B : I->bs) {
+    COX_TRY(dev_realloc(&B.pslot, cap));
+    for (int k = 0; k < 2; ++k) {
+      COX_TRY(dev_realloc(&B.skey[k], cap));
+      COX_TRY(dev_realloc(&B.sval[k], cap));
+    }
+    COX_TRY(dev_realloc(&B.head, cap));
+    COX_TRY(dev_realloc(&B.bstart, cap));
   }
-  COX_TRY(dev_realloc(&I->head, cap));
-  COX_TRY(dev_realloc(&I->bstart, cap));
   COX_TRY(dev_realloc(&I->own_xyz, static_cast<size_t>(cap) * 3));
   COX_TRY(dev_realloc(&I->own_rgba, static_cast<size_t>(cap) * 4));
   COX_TRY(dev_realloc(&I->depth_flag, cap));
-  I->fh_cap = next_pow2(static_cast<u64>(cap) + cap / 2);  // load factor <= 2/3 even if every point is its own bundle
-  for (int b = 0; b < 2; ++b) {
-    COX_TRY(dev_realloc(&I->fh_keys2[b], static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
-    I->fh_first2[b] = reinterpret_cast<u32*>(I->fh_keys2[b] + I->fh_cap);
-  }
   COX_TRY(alloc_sort_ws(&I->sort_pts, cap));
   // records: the worst case (every ray at maximum length) always fits, so a frame can never overflow
   // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
@@ -1184,19 +1204,22 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   const u64 want = static_cast<u64>(cap) * I->steps_max;
   const u64 limit = 0x7FFFFFF0ull;
   const u32 rcap = static_cast<u32>(std::min(want, limit));
-  for (int k = 0; k < 2; ++k) {
-    COX_TRY(dev_realloc(&I->rec_key[k], rcap));
-    COX_TRY(dev_realloc(&I->rec_ray[k], rcap));
-  }
   const u32 wave_cap = rcap / 64 + 2;
-  COX_TRY(dev_realloc(&I->piece_front, wave_cap));
-  COX_TRY(dev_realloc(&I->piece_back, wave_cap));
-  COX_TRY(dev_realloc(&I->piece_wsum, static_cast<size_t>(wave_cap) * 2));
+  for (RecordSet& S : I->rs) {
+    for (int k = 0; k < 2; ++k) {
+      COX_TRY(dev_realloc(&S.rec_key[k], rcap));
+      COX_TRY(dev_realloc(&S.rec_ray[k], rcap));
+    }
+    COX_TRY(dev_realloc(&S.piece_front, wave_cap));
+    COX_TRY(dev_realloc(&S.piece_back, wave_cap));
+    COX_TRY(dev_realloc(&S.piece_wsum, static_cast<size_t>(wave_cap) * 2));
+  }
   COX_TRY(alloc_sort_ws(&I->sort_rec, rcap));
   const u32 need_scan = scan_num_blocks(cap) + 2;
   if (need_scan > I->scan_cap) {
     COX_TRY(dev_realloc(&I->scanws_a.block_sums, need_scan));
     COX_TRY(dev_realloc(&I->scanws_b.block_sums, need_scan));
+    COX_TRY(dev_realloc(&I->scanws_d.block_sums, need_scan));
     I->scan_cap = need_scan;
   }
   I->rcap = rcap;
@@ -1241,14 +1264,13 @@ static inline dim3 grid_for(u32 n, u32 block = 256, u32 cap = 0x7FFFFFFFu) { ret
 // hints never affect results (every kernel grid-strides over device-side counts), only occupancy.
 static void refresh_hints(cox_integrator* I) {
   if (I->counts_frame == 0) return;
-  const Counters& c = I->h_ring[(I->counts_frame) % kStatRing];  // may be one frame stale or mid-copy: harmless
+  const Counters& c = I->h_ring[(I->counts_frame) % kStatRing];  // may be a few frames stale or mid-copy: harmless
   const u32 rec = c.n_records, rays = c.n_ray_slots;
   if (rec) I->hint_records = std::max<u32>(rec + rec / 4 + 65536, I->hint_records / 2);
   if (rays) I->hint_rays = std::max<u32>(rays + rays / 4 + 1024, I->hint_rays / 2);
 }
 
-// enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the stream reaches
-// the end of the frame
+// enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
 static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
   cox_layer* Lh = I->layer;
   COX_TRY(ensure_capacity(I, n));
@@ -1256,138 +1278,148 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   P.frame_id = ++Lh->frame_id;
   LayerView L{Lh->voxels, Lh->ht_keys, Lh->ht_vals, Lh->ht_stamp, Lh->ht_ord, Lh->block_keys, Lh->d_nblocks, Lh->ht_cap - 1, static_cast<u32>(Lh->capacity)};
   I->frame_no += 1;
-  const int buf = static_cast<int>(I->frame_no & 1u);
-  hipStream_t sa = I->stream_a, sb = I->stream;
-  RayArrays R = I->rays2[buf];
-  Counters* C = I->d_cnt2 + buf;
-  u64* fh_keys = I->fh_keys2[buf];
-  u32* fh_first = I->fh_first2[buf];
+  FrameSet& F = I->fs[I->frame_no % kFrameSets];
+  BundleSet& B = I->bs[I->frame_no & 1u];
+  RecordSet& S = I->rs[I->frame_no & 1u];
+  hipStream_t s_a1 = I->st[0], s_a2 = I->st[1], s_b1 = I->st[2], s_b2 = I->st[3];
+  RayArrays R = F.rays;
+  Counters* C = F.cnt;
   I->last = cox_frame_stats{};
   I->last.n_points = n;
   I->last_has_counts = false;
   if (n == 0) return COX_OK;
   refresh_hints(I);
-
-  // ---------------- stage A: rays of this frame (input only) ----------------
-  if (I->b_used[buf]) COX_HIP(hipStreamWaitEvent(sa, I->ev_b_done[buf], 0));  // frame t-2 is done with this buffer set
-  COX_HIP(hipMemsetAsync(C, 0, sizeof(Counters), sa));
   const u32 fh_mask = I->fh_cap - 1;
   const bool merged = I->method == COX_METHOD_MERGED;
-  u32 ray_hint;
+  u32 ray_hint = n;
+
+  // ---------------- stage A1: bundle hash + bundling sort (input only) ----------------
+  if (F.used) COX_HIP(hipStreamWaitEvent(s_a1, F.done, 0));  // frame t-4 is done with this frame set
+  if (B.used) COX_HIP(hipStreamWaitEvent(s_a1, B.done, 0));  // frame t-2's A2 is done with this bundle set
+  COX_HIP(hipMemsetAsync(C, 0, sizeof(Counters), s_a1));
+  u32 np2 = 0;
+  const u32 *sk = nullptr, *sv = nullptr;
   if (merged) {
-    const u32 np2 = next_pow2(static_cast<u64>(n) + 1);
-    COX_HIP(hipMemsetAsync(fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, sa));
-    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, sa, P, xyz, fh_keys, fh_first, fh_mask, I->pslot, C);
-    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, sa, n, np2, fh_keys, fh_first, I->pslot, I->skey[0], I->sval[0]);
+    np2 = next_pow2(static_cast<u64>(n) + 1);
+    COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s_a1));
+    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s_a1, P, xyz, F.fh_keys, F.fh_first, fh_mask, B.pslot, C);
+    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s_a1, n, np2, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0]);
     const int kbits = ceil_log2(np2) + 1;  // + clearing bit; kInvalid's low bits exceed every valid key
-    const int cur = radix_sort_pairs<11>(I->skey[0], I->sval[0], I->skey[1], I->sval[1], nullptr, n, n, kbits, false, 0, I->sort_pts, sa);
-    const u32* sk = I->skey[cur];
-    const u32* sv = I->sval[cur];
-    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, sa, n, sk, I->head);
+    const int cur = radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], nullptr, n, n, kbits, false, 0, I->sort_pts, nullptr, s_a1);
+    sk = B.skey[cur];
+    sv = B.sval[cur];
+  }
+  COX_HIP(hipEventRecord(I->ev_a1, s_a1));
+
+  // ---------------- stage A2: bundle boundaries + sequential means -> rays ----------------
+  COX_HIP(hipStreamWaitEvent(s_a2, I->ev_a1, 0));
+  if (merged) {
+    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, s_a2, n, sk, B.head);
     // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
-    exclusive_scan_u32(I->head, I->head, nullptr, n, n, &C->n_rays, I->scanws_a, sa);
-    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, sa, n, sk, I->head, I->bstart, C);
+    exclusive_scan_u32(B.head, B.head, nullptr, n, n, &C->n_rays, I->scanws_a, s_a2);
+    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s_a2, n, sk, B.head, B.bstart, C);
     ray_hint = I->hint_rays ? std::min(I->hint_rays, n) : std::min<u32>(n, 16384);
     hipEvent_t m0 = nullptr, m1 = nullptr;
     if (I->profiling) {
       COX_HIP(hipEventCreate(&m0));
       COX_HIP(hipEventCreate(&m1));
-      COX_HIP(hipEventRecord(m0, sa));
+      COX_HIP(hipEventRecord(m0, s_a2));
     }
-    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 128u, 256, 8192), dim3(256), 0, sa, P, np2, xyz, rgba, sk, sv, I->bstart, R, C);
+    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 128u, 256, 8192), dim3(256), 0, s_a2, P, np2, xyz, rgba, sk, sv, B.bstart, R, C);
     if (I->profiling) {
-      COX_HIP(hipEventRecord(m1, sa));
+      COX_HIP(hipEventRecord(m1, s_a2));
       I->merge_events.emplace_back(m0, m1);
     }
   } else {
-    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, sa, P, xyz, rgba, R, C);
-    ray_hint = n;
+    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s_a2, P, xyz, rgba, R, C);
   }
-  COX_HIP(hipEventRecord(I->ev_a_done[buf], sa));
+  COX_HIP(hipEventRecord(I->ev_a2, s_a2));
+  COX_HIP(hipEventRecord(B.done, s_a2));
+  B.used = true;
 
-  // ---------------- stage B: update the layer ----------------
-  COX_HIP(hipStreamWaitEvent(sb, I->ev_a_done[buf], 0));
-  // record offsets over the ray slots in use
-  exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws_b, sb);
-  // allocate + stamp blocks, then emit records
+  // ---------------- stage B1: record offsets, block allocation, records, record sort ----------------
+  COX_HIP(hipStreamWaitEvent(s_b1, I->ev_a2, 0));
+  if (S.used) COX_HIP(hipStreamWaitEvent(s_b1, S.done, 0));  // frame t-2's B2 is done with this record set
+  exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws_b, s_b1);
   if (merged) {
     // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
-    hipLaunchKernelGGL(k_touch_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, sb, P, R, L, I->touched_slots, I->rec_key[1], I->rcap, C, Lh->d_err,
-                       fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, sb, P, R, L, I->rec_key[1], I->rec_key[0], I->rec_ray[0], I->rcap, C,
-                       I->sort_rec.info, fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_touch_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s_b1, P, R, L, S.touched_slots, S.rec_key[1], I->rcap, C, Lh->d_err,
+                       F.fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s_b1, P, R, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, C,
+                       S.sort_info, F.fh_keys, fh_mask);
   } else {
-    hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, sb, P, R, L, I->touched_slots, C, Lh->d_err, fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, sb, P, R, L, I->rec_key[0], I->rec_ray[0], I->rcap, C, I->sort_rec.info, fh_keys,
+    hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, s_b1, P, R, L, S.touched_slots, C, Lh->d_err, F.fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, s_b1, P, R, L, S.rec_key[0], S.rec_ray[0], I->rcap, C, S.sort_info, F.fh_keys,
                        fh_mask);
   }
   const u32 rec_hint = I->hint_records ? std::min(I->hint_records, I->rcap) : std::min<u32>(I->rcap, std::max<u32>(1u << 20, n * 4u));
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits
-  (void)radix_sort_pairs<11>(I->rec_key[0], I->rec_ray[0], I->rec_key[1], I->rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, sb);
-  RecordView V{{I->rec_key[0], I->rec_key[1]}, {I->rec_ray[0], I->rec_ray[1]}, I->sort_rec.info, &C->n_records};
+  (void)radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, S.sort_info,
+                             s_b1);
+  COX_HIP(hipEventRecord(I->ev_b1, s_b1));
+
+  // ---------------- stage B2: apply ----------------
+  COX_HIP(hipStreamWaitEvent(s_b2, I->ev_b1, 0));
+  RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &C->n_records};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->profiling) {
     COX_HIP(hipEventCreate(&e0));
     COX_HIP(hipEventCreate(&e1));
-    COX_HIP(hipEventRecord(e0, sb));
+    COX_HIP(hipEventRecord(e0, s_b2));
   }
-  hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, sb, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum,
-                     C);
-  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, sb, P, R, L, I->touched_slots, V, I->piece_front, I->piece_back, I->piece_wsum, C, Lh->d_err);
+  hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, s_b2, P, R, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, C);
+  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s_b2, P, R, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, C, Lh->d_err);
   if (I->profiling) {
-    COX_HIP(hipEventRecord(e1, sb));
+    COX_HIP(hipEventRecord(e1, s_b2));
     I->apply_events.emplace_back(e0, e1);
   }
-  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], C, sizeof(Counters), hipMemcpyDeviceToHost, sb));
-  COX_HIP(hipEventRecord(I->ev_b_done[buf], sb));
-  I->b_used[buf] = true;
+  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], C, sizeof(Counters), hipMemcpyDeviceToHost, s_b2));
+  COX_HIP(hipEventRecord(F.done, s_b2));
+  COX_HIP(hipEventRecord(S.done, s_b2));
+  F.used = true;
+  S.used = true;
   I->counts_frame = I->frame_no;
   I->last_has_counts = true;
   COX_HIP(hipGetLastError());
   return COX_OK;
 }
 
-// wait for the stream, fold the last frame's counters into the stats, return deferred errors
-static int integrator_finish(cox_integrator* I) {
-  COX_HIP(hipStreamSynchronize(I->stream_a));
-  COX_HIP(hipStreamSynchronize(I->stream));
-  u32 err = 0;
-  if (I->last_has_counts) {
-    const Counters& c = I->h_ring[I->frame_no % kStatRing];
-    I->last.n_valid = c.n_valid;
-    I->last.n_rays = c.n_rays;
-    I->last.n_updates = c.n_updates;
-    I->last.n_touched_voxels = c.n_voxels;
-    I->last.n_touched_blocks = c.n_touched;
-    I->last.n_new_blocks = c.n_new_blocks;
-    if (c.n_records) I->hint_records = std::max<u32>(I->hint_records, c.n_records + c.n_records / 4 + 65536);
+static void fold_counters(cox_integrator* I) {
+  if (!I->last_has_counts) return;
+  const Counters& c = I->h_ring[I->frame_no % kStatRing];
+  I->last.n_valid = c.n_valid;
+  I->last.n_rays = c.n_rays;
+  I->last.n_updates = c.n_updates;
+  I->last.n_touched_voxels = c.n_voxels;
+  I->last.n_touched_blocks = c.n_touched;
+  I->last.n_new_blocks = c.n_new_blocks;
+  if (c.n_records) I->hint_records = std::max<u32>(I->hint_records, c.n_records + c.n_records / 4 + 65536);
+}
+
+static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc) {
+  for (auto& ev : evs) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      *ms_acc += ms;
+      *n_acc += 1;
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
   }
+  evs.clear();
+}
+
+// wait for all stages, fold the last frame's counters into the stats, return deferred errors
+static int integrator_finish(cox_integrator* I) {
+  COX_TRY(sync_all(I));
+  fold_counters(I);
   // errors of every frame since the last sync are sticky in the layer's device error word; report them once
   u32 lerr = 0;
   COX_HIP(hipMemcpy(&lerr, I->layer->d_err, sizeof(u32), hipMemcpyDeviceToHost));
   if (lerr) COX_HIP(hipMemset(I->layer->d_err, 0, sizeof(u32)));
-  err |= lerr;
-  for (auto& ev : I->apply_events) {
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
-      I->apply_ms += ms;
-      I->apply_launches += 1;
-    }
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
-  I->apply_events.clear();
-  for (auto& ev : I->merge_events) {
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
-      I->merge_ms += ms;
-      I->merge_launches += 1;
-    }
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
-  I->merge_events.clear();
-  return err_bits_to_status(err);
+  drain_events(I->apply_events, &I->apply_ms, &I->apply_launches);
+  drain_events(I->merge_events, &I->merge_ms, &I->merge_launches);
+  return err_bits_to_status(lerr);
 }
 
 extern "C" {
@@ -1405,17 +1437,28 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   I->cfg = *cfg;
   I->method = method;
   int st = COX_OK;
-  if (hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
-  if (st == COX_OK && hipStreamCreateWithFlags(&I->stream_a, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
-  for (int b = 0; b < 2 && st == COX_OK; ++b) {
-    if (hipEventCreateWithFlags(&I->ev_a_done[b], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
-    if (st == COX_OK && hipEventCreateWithFlags(&I->ev_b_done[b], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  auto ev = [&](hipEvent_t* e) {
+    if (st == COX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  };
+  for (int k = 0; k < 4; ++k)
+    if (st == COX_OK && hipStreamCreateWithFlags(&I->st[k], hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  ev(&I->ev_a1);
+  ev(&I->ev_a2);
+  ev(&I->ev_b1);
+  for (FrameSet& F : I->fs) {
+    ev(&F.done);
+    if (st == COX_OK) st = dev_realloc(&F.cnt, 1);
   }
-  if (st == COX_OK && hipMalloc(reinterpret_cast<void**>(&I->d_cnt2), 2 * sizeof(Counters)) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
+  for (BundleSet& B : I->bs) ev(&B.done);
+  for (RecordSet& S : I->rs) {
+    ev(&S.done);
+    if (st == COX_OK) st = dev_realloc(&S.touched_slots, layer->ht_cap);  // one entry per block key the table can hold
+    if (st == COX_OK) st = dev_realloc(&S.sort_info, 1);
+    if (st == COX_OK && hipMemset(S.sort_info, 0, sizeof(SortInfo)) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  }
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK) st = dev_realloc(&I->d_depth_n, 1);
-  if (st == COX_OK) st = dev_realloc(&I->touched_slots, layer->ht_cap);  // one entry per block key the table can hold
   if (st == COX_OK) {
     memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
     st = ensure_capacity(I, 640 * 480);
@@ -1431,31 +1474,43 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
 void cox_integrator_destroy(cox_integrator_t* I) {
   if (!I) return;
   (void)hipSetDevice(I->layer->device);
-  if (I->stream_a) (void)hipStreamSynchronize(I->stream_a);
-  if (I->stream) (void)hipStreamSynchronize(I->stream);
+  (void)sync_all(I);
   for (auto* evs : {&I->apply_events, &I->merge_events})
-    for (auto& ev : *evs) {
-      (void)hipEventDestroy(ev.first);
-      (void)hipEventDestroy(ev.second);
+    for (auto& e : *evs) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
     }
-  std::vector<void*> ptrs = {I->pslot, I->skey[0], I->skey[1], I->sval[0], I->sval[1], I->head, I->bstart, I->own_xyz, I->own_rgba, I->depth_flag,
-                             I->rec_key[0], I->rec_key[1], I->rec_ray[0], I->rec_ray[1], I->piece_front, I->piece_back, I->piece_wsum, I->touched_slots,
-                             I->sort_pts.counts, I->sort_pts.totals, I->sort_pts.info, I->sort_rec.counts, I->sort_rec.totals, I->sort_rec.info,
-                             I->scanws_a.block_sums, I->scanws_b.block_sums, I->d_cnt2, I->d_depth_n};
-  for (int b = 0; b < 2; ++b) {
-    const RayArrays& R = I->rays2[b];
+  std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
+                             I->sort_rec.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums};
+  std::vector<hipEvent_t> events = {I->ev_a1, I->ev_a2, I->ev_b1};
+  for (FrameSet& F : I->fs) {
+    const RayArrays& R = F.rays;
     for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
                     static_cast<void*>(R.flags), static_cast<void*>(R.key), static_cast<void*>(R.nsteps), static_cast<void*>(R.rec_off),
-                    static_cast<void*>(I->fh_keys2[b])})
+                    static_cast<void*>(F.fh_keys), static_cast<void*>(F.cnt)})
       ptrs.push_back(p);
-    if (I->ev_a_done[b]) (void)hipEventDestroy(I->ev_a_done[b]);
-    if (I->ev_b_done[b]) (void)hipEventDestroy(I->ev_b_done[b]);
+    events.push_back(F.done);
+  }
+  for (BundleSet& B : I->bs) {
+    for (void* p : {static_cast<void*>(B.pslot), static_cast<void*>(B.skey[0]), static_cast<void*>(B.skey[1]), static_cast<void*>(B.sval[0]),
+                    static_cast<void*>(B.sval[1]), static_cast<void*>(B.head), static_cast<void*>(B.bstart)})
+      ptrs.push_back(p);
+    events.push_back(B.done);
+  }
+  for (RecordSet& S : I->rs) {
+    for (void* p : {static_cast<void*>(S.rec_key[0]), static_cast<void*>(S.rec_key[1]), static_cast<void*>(S.rec_ray[0]), static_cast<void*>(S.rec_ray[1]),
+                    static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots),
+                    static_cast<void*>(S.sort_info)})
+      ptrs.push_back(p);
+    events.push_back(S.done);
   }
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t e : events)
+    if (e) (void)hipEventDestroy(e);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
-  if (I->stream_a) (void)hipStreamDestroy(I->stream_a);
-  if (I->stream) (void)hipStreamDestroy(I->stream);
+  for (int k = 0; k < 4; ++k)
+    if (I->st[k]) (void)hipStreamDestroy(I->st[k]);
   delete I;
 }
 
@@ -1471,10 +1526,11 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
-  COX_HIP(hipStreamSynchronize(I->stream_a));  // the staging buffers may still feed an earlier frame
+  COX_TRY(sync_all(I));  // the staging buffers may still feed an earlier frame
   if (n) {
-    COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->stream_a));
-    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->stream_a));
+    COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st[0]));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->st[0]));
+    if (I->method != COX_METHOD_MERGED) COX_HIP(hipStreamSynchronize(I->st[0]));  // simple: the first consumer runs on the A2 stream after an empty A1
   }
   COX_TRY(integrate_device(I, T_G_C, I->own_xyz, rgba ? I->own_rgba : nullptr, static_cast<u32>(n), freespace));
   return integrator_finish(I);
@@ -1486,10 +1542,10 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   COX_HIP(hipSetDevice(I->layer->device));
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
-  hipStream_t s = I->stream_a;
-  COX_HIP(hipStreamSynchronize(s));  // staging buffers
+  COX_TRY(sync_all(I));  // staging buffers
+  hipStream_t s = I->st[0];
   hipLaunchKernelGGL(k_depth_flags, grid_for(n), dim3(256), 0, s, depth_dev, n, I->depth_flag);
-  exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, I->d_depth_n, I->scanws_a, s);
+  exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, I->d_depth_n, I->scanws_d, s);
   hipLaunchKernelGGL(k_depth_points, grid_for(n), dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz,
                      I->own_rgba);
   // the point count feeds the "mixed" visiting order, which is a function of N: it has to reach the host
@@ -1511,17 +1567,8 @@ int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
   COX_ENTRY();
   if (!I || !stats) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
-  COX_HIP(hipStreamSynchronize(I->stream_a));
-  COX_HIP(hipStreamSynchronize(I->stream));
-  if (I->last_has_counts) {
-    const Counters& c = I->h_ring[I->frame_no % kStatRing];
-    I->last.n_valid = c.n_valid;
-    I->last.n_rays = c.n_rays;
-    I->last.n_updates = c.n_updates;
-    I->last.n_touched_voxels = c.n_voxels;
-    I->last.n_touched_blocks = c.n_touched;
-    I->last.n_new_blocks = c.n_new_blocks;
-  }
+  COX_TRY(sync_all(I));
+  fold_counters(I);
   *stats = I->last;
   return COX_OK;
 }
@@ -1546,7 +1593,6 @@ int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* 
   }
   return st;
 }
-
 
 int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launches[2], int reset) {
   COX_ENTRY();

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restr
     *p = run;
     run += v;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) info->parity = (pass + 1) & 1;  // this pass runs: its output buffer is current
+  if (host_bits < 0 && blockIdx.x == 0 && threadIdx.x == 0) info->parity = (pass + 1) & 1;  // this pass runs: its output buffer is current
 }
 
 // wave-wide "which lanes hold my digit" (RB ballots), restricted to lanes with valid == true
@@ -285,17 +285,16 @@ struct SortWorkspace {
   u32* counts = nullptr;   // [tiles_cap][2^11]
   u32 tiles_cap = 0;       // >= ceil(capacity / kRsTile)
   u32* totals = nullptr;   // [kRsMaxPasses][2^11], zeroed by the sort
-  SortInfo* info = nullptr;  // device
 };
 static inline u32 sort_num_tiles(u64 n) { return static_cast<u32>((n + kRsTile - 1) / kRsTile); }
 
 // Sorts (k0,v0) by key bits [0, nbits).  Buffers ping-pong; the buffer that holds the result is
 // returned when nbits is known on the host (bits_on_device == false).  Otherwise nbits is read from
-// ws.info->nbits (written by an earlier kernel of the frame), max_passes passes are enqueued (surplus
-// ones exit at once), the result buffer is reported in ws.info->parity (device) and -1 is returned.
+// info->nbits (written by an earlier kernel of the frame), max_passes passes are enqueued (surplus
+// ones exit at once), the result buffer is reported in info->parity (device) and -1 is returned.
 template <int RB>
 static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32* d_n, u32 n_max, u32 n_hint, int host_bits, bool bits_on_device,
-                                   int max_passes, const SortWorkspace& ws, hipStream_t s) {
+                                   int max_passes, const SortWorkspace& ws, SortInfo* info, hipStream_t s) {
   const u32 nt = sort_num_tiles(n_hint ? n_hint : 1);
   const u32 grid = nt < 1 ? 1 : (nt > 8192 ? 8192 : nt);
   int passes = max_passes;
@@ -305,9 +304,9 @@ static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32
   (void)hipMemsetAsync(ws.totals, 0, sizeof(u32) * kRsMaxPasses * (1u << 11), s);
   for (int p = 0; p < passes; ++p) {
     u32* totals = ws.totals + static_cast<size_t>(p) * (1u << 11);
-    hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
-    hipLaunchKernelGGL(k_rs_offsets<RB>, dim3((1u << RB) / 64u), dim3(kRsOffThreads), 0, s, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap, totals);
-    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, ws.info, hb, ws.counts, ws.tiles_cap);
+    hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_offsets<RB>, dim3((1u << RB) / 64u), dim3(kRsOffThreads), 0, s, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap);
   }
   return bits_on_device ? -1 : (passes & 1);
 }
