@@ -31,6 +31,12 @@ struct FrameParams {
   u32 frame_id;
   int use_const_weight, allow_clear, carving, use_dropoff, use_sparsity, anti_grazing, freespace;
   int cast_from_origin;
+  // inputs of the frame (device pointers) -- part of the parameter block so that kernel arguments stay the same
+  // from frame to frame and a stage can be replayed as a HIP graph
+  const float* xyz;
+  const uint8_t* rgba;
+  u32 np2;  // power of two > n_points (bundling sort key layout)
+  u32 pad;
 };
 
 struct F3 {

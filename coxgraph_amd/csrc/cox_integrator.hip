@@ -107,13 +107,14 @@ __device__ __forceinline__ u32 uniform_u32(u32 v) { return static_cast<u32>(__bu
 __device__ __forceinline__ float readlane_f32(float v, u32 lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
 // ---- simple: one ray per point, ray id = mixed-order sequence number --------------------------
-__global__ void __launch_bounds__(256) k_rays_simple(FrameParams P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba, RayArrays R,
+__global__ void __launch_bounds__(256) k_rays_simple(const FrameParams* __restrict__ Pp, RayArrays R,
                                                      Counters* cnt) {
+  const FrameParams P = *Pp;
   const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
   if (seq == 0) cnt->n_ray_slots = P.n_points;
   if (seq >= P.n_points) return;
   const u32 idx = mixed_index(seq, P.n_points);
-  const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  const F3 p{P.xyz[3 * idx], P.xyz[3 * idx + 1], P.xyz[3 * idx + 2]};
   bool clearing = false;
   const bool valid = point_valid(P, p, &clearing);
   u32 nsteps = 0, flags = 0;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) k_rays_simple(FrameParams P, const float*
     R.py[seq] = pg.y;
     R.pz[seq] = pg.z;
     R.w[seq] = voxel_weight(P, p);
-    R.color[seq] = pack_rgba_wire(rgba, idx);
+    R.color[seq] = pack_rgba_wire(P.rgba, idx);
   }
   R.flags[seq] = flags;
   R.nsteps[seq] = nsteps;
@@ -144,8 +145,9 @@ __global__ void __launch_bounds__(256) k_rays_simple(FrameParams P, const float*
 // wave that hold the same key elect one leader, which inserts the key in the per-frame hash once and records the
 // smallest sequence number of the group as a candidate for the bundle's first visit.  pslot is indexed by the
 // point's "mixed" sequence number, the order the bundling sort must start from.
-__global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const float* __restrict__ xyz, u64* __restrict__ fh_keys, u32* __restrict__ fh_first,
+__global__ void __launch_bounds__(256) k_bundle_insert(const FrameParams* __restrict__ Pp, u64* __restrict__ fh_keys, u32* __restrict__ fh_first,
                                                        u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
+  const FrameParams P = *Pp;
   const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 lane = lane_id();
   bool valid = false;
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const floa
   u32 seq = kInvalid;
   if (idx < P.n_points) {
     seq = mixed_sequence(idx, P.n_points);
-    const F3 p{xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    const F3 p{P.xyz[3 * idx], P.xyz[3 * idx + 1], P.xyz[3 * idx + 2]};
     bool clearing = false;
     valid = point_valid(P, p, &clearing);
     if (valid) {
@@ -202,10 +204,18 @@ __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams P, const floa
   const u64 m = __ballot(valid && slot != kInvalid);
   if (lane == 0 && m) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
 }
-// sort key of a point = (clearing ? np2 : 0) + first sequence number of its bundle; value = seq
-__global__ void __launch_bounds__(256) k_bundle_keys(u32 n, u32 np2, const u64* __restrict__ fh_keys, const u32* __restrict__ fh_first,
-                                                     const u32* __restrict__ pslot, u32* __restrict__ skey, u32* __restrict__ sval) {
+// sort key of a point = (clearing ? np2 : 0) + first sequence number of its bundle; value = seq.  Also publishes the
+// key width of the bundling sort.
+__global__ void __launch_bounds__(256) k_bundle_keys(const FrameParams* __restrict__ Pp, const u64* __restrict__ fh_keys, const u32* __restrict__ fh_first,
+                                                     const u32* __restrict__ pslot, u32* __restrict__ skey, u32* __restrict__ sval, SortInfo* sort_info) {
+  const u32 n = Pp->n_points, np2 = Pp->np2;
   const u32 seq = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq == 0) {
+    u32 bits = 1;  // clearing bit + log2(np2); kInvalid's low bits exceed every valid key
+    while ((1u << (bits - 1)) < np2) ++bits;
+    sort_info->nbits = bits;
+    sort_info->parity = 0;
+  }
   if (seq >= n) return;
   const u32 slot = pslot[seq];
   u32 k = kInvalid;
@@ -213,17 +223,27 @@ __global__ void __launch_bounds__(256) k_bundle_keys(u32 n, u32 np2, const u64* 
   skey[seq] = k;
   sval[seq] = seq;
 }
-__global__ void __launch_bounds__(256) k_bundle_heads(u32 n, const u32* __restrict__ skey, u32* __restrict__ head) {
+// the two ping-pong buffers of the bundling sort + where its result ended up
+struct BundleView {
+  const u32* key[2];
+  const u32* val[2];
+  const SortInfo* info;
+};
+__global__ void __launch_bounds__(256) k_bundle_heads(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ head) {
+  const u32 n = Pp->n_points;
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const u32* __restrict__ skey = V.key[V.info->parity & 1u];
   const u32 k = skey[i];
   head[i] = (k != kInvalid && (i == 0 || skey[i - 1] != k)) ? 1u : 0u;
 }
-__global__ void __launch_bounds__(256) k_bundle_starts(u32 n, const u32* __restrict__ skey, const u32* __restrict__ head_scan, u32* __restrict__ bstart,
+__global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ head_scan, u32* __restrict__ bstart,
                                                        Counters* cnt) {
+  const u32 n = Pp->n_points;
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) cnt->n_ray_slots = cnt->n_rays;  // n_rays = number of bundles, written by the scan before this kernel
   if (i >= n) return;
+  const u32* __restrict__ skey = V.key[V.info->parity & 1u];
   const u32 k = skey[i];
   if (k != kInvalid && (i == 0 || skey[i - 1] != k)) bstart[head_scan[i]] = i;
 }
@@ -246,9 +266,14 @@ __device__ __forceinline__ void wave_lds_handover() {
   __builtin_amdgcn_wave_barrier();
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
-__global__ void __launch_bounds__(256) k_bundle_merge(FrameParams P, u32 np2, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba,
-                                                      const u32* __restrict__ skey, const u32* __restrict__ sval, const u32* __restrict__ bstart,
-                                                      RayArrays R, Counters* cnt) {
+__global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ bstart, RayArrays R, Counters* cnt) {
+  const FrameParams P = *Pp;
+  const u32 np2 = P.np2;
+  const float* __restrict__ xyz = P.xyz;
+  const uint8_t* __restrict__ rgba = P.rgba;
+  const u32 spar = uniform_u32(V.info->parity & 1u);
+  const u32* __restrict__ skey = V.key[spar];
+  const u32* __restrict__ sval = V.val[spar];
   __shared__ MergeOp ops[4][64][4];
   const u32 n_bundles = uniform_u32(cnt->n_rays);
   const u32 n_valid = uniform_u32(cnt->n_valid);
@@ -382,8 +407,9 @@ __device__ __forceinline__ bool grazing_skip(const FrameParams& P, const u64* fh
   return ht_find(fh_keys, fh_mask, k) != kInvalid;
 }
 
-__global__ void __launch_bounds__(256) k_touch(FrameParams P, RayArrays R, LayerView L, u32* __restrict__ touched_slots, Counters* cnt, u32* layer_err,
+__global__ void __launch_bounds__(256) k_touch(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ touched_slots, Counters* cnt, u32* layer_err,
                                                const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const FrameParams P = *Pp;
   const u32 n_slots = cnt->n_ray_slots;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_slots; r += gridDim.x * blockDim.x) {
     const u32 ns = R.nsteps[r];
@@ -430,8 +456,9 @@ __global__ void __launch_bounds__(256) k_touch(FrameParams P, RayArrays R, Layer
 // ---- emit: (voxel id, ray id) records, ray-major ------------------------------------------------
 // voxel id = ordinal of the block within this frame << 12 | linear voxel index.  Also publishes the key
 // width the record sort needs.
-__global__ void __launch_bounds__(256) k_emit(FrameParams P, RayArrays R, LayerView L, u32* __restrict__ rec_key, u32* __restrict__ rec_ray, u32 rec_cap,
+__global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ rec_key, u32* __restrict__ rec_ray, u32 rec_cap,
                                               Counters* cnt, SortInfo* sort_info, const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const FrameParams P = *Pp;
   const u32 n_slots = cnt->n_ray_slots;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
@@ -587,8 +614,9 @@ __device__ __forceinline__ void touch_block(const FrameParams& P, const LayerVie
   }
 }
 
-__global__ void __launch_bounds__(256) k_touch_wave(FrameParams P, RayArrays R, LayerView L, u32* __restrict__ touched_slots, u32* __restrict__ path_out,
+__global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ touched_slots, u32* __restrict__ path_out,
                                                     u32 rec_cap, Counters* cnt, u32* layer_err, const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const FrameParams P = *Pp;
   __shared__ float lds_t[4][3 * kAxisCap];
   __shared__ u32 lds_path[4][3 * kAxisCap];
   const u32 n_slots = uniform_u32(cnt->n_ray_slots);
@@ -647,9 +675,10 @@ __global__ void __launch_bounds__(256) k_touch_wave(FrameParams P, RayArrays R, 
   }
 }
 
-__global__ void __launch_bounds__(256) k_emit_wave(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ path_in, u32* __restrict__ rec_key,
+__global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ path_in, u32* __restrict__ rec_key,
                                                    u32* __restrict__ rec_ray, u32 rec_cap, Counters* cnt, SortInfo* sort_info,
                                                    const u64* __restrict__ fh_keys, u32 fh_mask) {
+  const FrameParams P = *Pp;
   const u32 n_slots = uniform_u32(cnt->n_ray_slots);
   const bool overflow = uniform_u32(cnt->n_records) > rec_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -775,9 +804,10 @@ __device__ __forceinline__ bool foldable_update(const FrameParams& P, float sdf,
   return saturating_update(P, sdf, uw) && uw == truncf(uw) && uw < 65536.0f;
 }
 
-__global__ void __launch_bounds__(256) k_apply_eval(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
+__global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
                                                     u32* __restrict__ piece_front, u32* __restrict__ piece_back, u32* __restrict__ piece_wsum,
                                                     Counters* cnt) {
+  const FrameParams P = *Pp;
   __shared__ u32 blk_updates, blk_voxels, blk_long;
   if (threadIdx.x == 0) {
     blk_updates = 0;
@@ -964,9 +994,10 @@ __device__ __forceinline__ bool fold_pieces(const FrameParams& P, Voxel& v, u32 
   return true;
 }
 
-__global__ void __launch_bounds__(256) k_apply_long(FrameParams P, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
+__global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
                                                     const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
                                                     const u32* __restrict__ piece_wsum, const Counters* cnt, u32* layer_err) {
+  const FrameParams P = *Pp;
   // last kernel of the frame: make this frame's error bits sticky until the host next looks
   if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
   const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
@@ -1066,24 +1097,33 @@ __global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ 
 //   A2  bundle boundaries + sequential means  (-> ray arrays)         stream[1]
 //   B1  record offsets, touch, emit, sort     (allocates blocks)      stream[2]
 //   B2  apply                                 (writes voxels)         stream[3]
-// (simple integrator: A1 is empty, A2 is k_rays_simple.)  B1 of frame t+1 beside B2 of frame t is safe: B1 only
-// inserts new hash entries / bumps the pool and restamps ordinals that B2 never reads (it goes through its own
-// frame's touched_slots), B2 only writes voxels.  Buffers are replicated by lifetime: what lives from A1 to B2
-// (counters, ray arrays, bundle hash) x4, A1->A2 (bundling sort buffers) x2, B1->B2 (records, touched blocks,
-// piece summaries, sort info) x2.  Events order producer -> consumer and consumer -> next writer of the same copy.
+// (simple integrator: A1 only uploads the parameter block, A2 is k_rays_simple.)  B1 of frame t+1 beside B2 of
+// frame t is safe: B1 only inserts new hash entries / bumps the pool and restamps ordinals that B2 never reads (it
+// goes through its own frame's touched_slots), B2 only writes voxels.  Buffers are replicated by lifetime: what
+// lives from A1 to B2 (parameter block, counters, ray arrays, bundle hash) x4, A1->A2 (bundling sort buffers) x2,
+// B1->B2 (records, touched blocks, piece summaries, sort info) x2.  Events order producer -> consumer and
+// consumer -> next writer of the same copy.
+//
+// Every per-frame quantity (pose, point count, input pointers, frame id) lives in a device-side parameter block and
+// every count in device counters, so the kernel arguments and grids of a stage never change: each stage is captured
+// once per buffer combination into a HIP graph (4 stages x 4 combinations) and replayed -- one graph launch instead
+// of ~12 kernel launches per stage, which lifts the host-side launch-rate limit (~3 000 frames/s eager).
 constexpr int kStatRing = 8;
 constexpr int kFrameSets = 4;
 
 struct FrameSet {  // lives A1 .. B2
+  FrameParams* d_params = nullptr;
   Counters* cnt = nullptr;
   RayArrays rays{};
   u64* fh_keys = nullptr;  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
   u32* fh_first = nullptr;
-  hipEvent_t done = nullptr;  // B2 of the frame that used this set
+  hipEvent_t done = nullptr;           // B2 of the frame that used this set
+  hipEvent_t params_copied = nullptr;  // the H2D copy of the parameter block has executed (host may rewrite the pinned slot)
   bool used = false;
 };
 struct BundleSet {  // lives A1 .. A2
   u32 *pslot = nullptr, *skey[2] = {nullptr, nullptr}, *sval[2] = {nullptr, nullptr}, *head = nullptr, *bstart = nullptr;
+  SortInfo* sort_info = nullptr;
   hipEvent_t done = nullptr;  // A2 of the frame that used this set
   bool used = false;
 };
@@ -1100,11 +1140,13 @@ struct cox_integrator {
   cox_layer* layer = nullptr;
   cox_tsdf_config cfg;
   int method = 0;
-  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // A1, A2, B1, B2
+  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // stream of stage A1, A2, B1, B2 (st[1] == st[0], st[3] == st[2]: see create)
+  int n_streams = 2;
   hipEvent_t ev_a1 = nullptr, ev_a2 = nullptr, ev_b1 = nullptr;  // per-frame hand-over events (re-recorded every frame)
   FrameSet fs[kFrameSets];
   BundleSet bs[2];
   RecordSet rs[2];
+  FrameParams* h_params = nullptr;  // pinned, kFrameSets entries
   u32 pcap = 0, rcap = 0, fh_cap = 0;
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
   float* own_xyz = nullptr;  // staging for host / depth inputs
@@ -1116,11 +1158,12 @@ struct cox_integrator {
   u32 scan_cap = 0;
   Counters* h_ring = nullptr;  // pinned, kStatRing entries
   uint64_t frame_no = 0;       // frames enqueued
-  uint64_t counts_frame = 0;   // frame whose end-of-frame counters were last enqueued (0 = none)
   cox_frame_stats last{};      // host-known part of the last frame's stats
   bool last_has_counts = false;
-  u32 hint_records = 0, hint_rays = 0;
-  // timing of individual kernels (bench roofline)
+  // stage graphs: [stage][frame set index] (the bundle / record set index is the frame set index & 1)
+  bool use_graphs = true;
+  hipGraphExec_t graphs[4][kFrameSets] = {};
+  // timing of individual kernels (bench roofline); forces eager launches
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events, merge_events;
   double apply_ms = 0.0, merge_ms = 0.0;
@@ -1162,13 +1205,22 @@ static u32 max_steps_per_ray(const cox_integrator* I) {
 
 static int sync_all(cox_integrator* I) {
   for (int k = 0; k < 4; ++k)
-    if (I->st[k]) COX_HIP(hipStreamSynchronize(I->st[k]));
+    if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
   return COX_OK;
+}
+
+static void drop_graphs(cox_integrator* I) {
+  for (auto& row : I->graphs)
+    for (hipGraphExec_t& g : row) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
 }
 
 static int ensure_capacity(cox_integrator* I, u32 n) {
   if (n <= I->pcap) return COX_OK;
   COX_TRY(sync_all(I));
+  drop_graphs(I);  // they hold the old pointers and grids
   const u32 cap = std::max<u32>(n, 1024);
   I->fh_cap = next_pow2(static_cast<u64>(cap) + cap / 2);  // load factor <= 2/3 even if every point is its own bundle
   for (FrameSet& F : I->fs) {
@@ -1227,9 +1279,10 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   return COX_OK;
 }
 
-static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n, int freespace) {
+static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n, int freespace, const float* xyz, const uint8_t* rgba) {
   const cox_tsdf_config& c = I->cfg;
   FrameParams P;
+  memset(&P, 0, sizeof(P));
   P.qw = T[0];
   P.qx = T[1];
   P.qy = T[2];
@@ -1255,130 +1308,199 @@ static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n,
   P.anti_grazing = (I->method == COX_METHOD_MERGED) ? c.enable_anti_grazing : 0;
   P.freespace = freespace;
   P.cast_from_origin = 1;
+  P.xyz = xyz;
+  P.rgba = rgba;
+  P.np2 = next_pow2(static_cast<u64>(n) + 1);
   return P;
 }
 
 static inline dim3 grid_for(u32 n, u32 block = 256, u32 cap = 0x7FFFFFFFu) { return dim3(std::min<u32>(cap, std::max<u32>(1, (n + block - 1) / block))); }
 
-// Refresh the grid-size hints from the newest end-of-frame counters that have certainly landed.  The
-// hints never affect results (every kernel grid-strides over device-side counts), only occupancy.
-static void refresh_hints(cox_integrator* I) {
-  if (I->counts_frame == 0) return;
-  const Counters& c = I->h_ring[(I->counts_frame) % kStatRing];  // may be a few frames stale or mid-copy: harmless
-  const u32 rec = c.n_records, rays = c.n_ray_slots;
-  if (rec) I->hint_records = std::max<u32>(rec + rec / 4 + 65536, I->hint_records / 2);
-  if (rays) I->hint_rays = std::max<u32>(rays + rays / 4 + 1024, I->hint_rays / 2);
+// ---- the four stages; identical whether launched eagerly or captured into a graph: no argument depends on the frame ----
+struct StageCtx {
+  cox_integrator* I;
+  FrameSet* F;
+  BundleSet* B;
+  RecordSet* S;
+  int slot;
+};
+static LayerView layer_view(const cox_layer* Lh) {
+  return LayerView{Lh->voxels, Lh->ht_keys, Lh->ht_vals, Lh->ht_stamp, Lh->ht_ord, Lh->block_keys, Lh->d_nblocks, Lh->ht_cap - 1, static_cast<u32>(Lh->capacity)};
+}
+static int points_sort_passes(const cox_integrator* I) { return (ceil_log2(next_pow2(static_cast<u64>(I->pcap) + 1)) + 1 + 10) / 11; }
+
+static int stage_a1(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
+  if (I->method == COX_METHOD_MERGED) {
+    const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
+    COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
+    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, I->fh_cap - 1, B.pslot, F.cnt);
+    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
+    (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I), I->sort_pts,
+                               B.sort_info, s);
+  }
+  return COX_OK;
+}
+static int stage_a2(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  const u32 n = I->pcap;
+  if (I->method == COX_METHOD_MERGED) {
+    BundleView V{{B.skey[0], B.skey[1]}, {B.sval[0], B.sval[1]}, B.sort_info};
+    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, s, F.d_params, V, B.head);
+    // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
+    exclusive_scan_u32(B.head, B.head, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
+    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
+    hipEvent_t m0 = nullptr, m1 = nullptr;
+    if (I->profiling) {
+      COX_HIP(hipEventCreate(&m0));
+      COX_HIP(hipEventCreate(&m1));
+      COX_HIP(hipEventRecord(m0, s));
+    }
+    hipLaunchKernelGGL(k_bundle_merge, dim3(4096), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt);
+    if (I->profiling) {
+      COX_HIP(hipEventRecord(m1, s));
+      I->merge_events.emplace_back(m0, m1);
+    }
+  } else {
+    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, F.d_params, F.rays, F.cnt);
+  }
+  return COX_OK;
+}
+static int stage_b1(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  RecordSet& S = *c.S;
+  const LayerView L = layer_view(I->layer);
+  const u32 fh_mask = I->fh_cap - 1;
+  const bool merged = I->method == COX_METHOD_MERGED;
+  exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, merged ? std::min<u32>(I->pcap, 32768) : I->pcap, &F.cnt->n_records,
+                     I->scanws_b, s);
+  if (merged) {
+    // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
+    hipLaunchKernelGGL(k_touch_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt, I->layer->d_err, F.fh_keys,
+                       fh_mask);
+    hipLaunchKernelGGL(k_emit_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
+                       F.fh_keys, fh_mask);
+  } else {
+    hipLaunchKernelGGL(k_touch, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, F.cnt, I->layer->d_err, F.fh_keys, fh_mask);
+    hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
+                       F.fh_keys, fh_mask);
+  }
+  // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits.
+  // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
+  (void)radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true, 3,
+                             I->sort_rec, S.sort_info, s);
+  return COX_OK;
+}
+static int stage_b2(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  RecordSet& S = *c.S;
+  const LayerView L = layer_view(I->layer);
+  RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &F.cnt->n_records};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (I->profiling) {
+    COX_HIP(hipEventCreate(&e0));
+    COX_HIP(hipEventCreate(&e1));
+    COX_HIP(hipEventRecord(e0, s));
+  }
+  hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
+  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
+                     I->layer->d_err);
+  if (I->profiling) {
+    COX_HIP(hipEventRecord(e1, s));
+    I->apply_events.emplace_back(e0, e1);
+  }
+  return COX_OK;
+}
+typedef int (*StageFn)(const StageCtx&, hipStream_t);
+static const StageFn kStages[4] = {stage_a1, stage_a2, stage_b1, stage_b2};
+
+// launch stage k of the frame in ctx on its stream: replay its graph (capturing it first if needed) or go eager
+static int run_stage(int k, const StageCtx& c) {
+  cox_integrator* I = c.I;
+  hipStream_t s = I->st[k];
+  if (!I->use_graphs || I->profiling) return kStages[k](c, s);
+  hipGraphExec_t& gx = I->graphs[k][c.slot];
+  if (!gx) {
+    hipGraph_t g = nullptr;
+    COX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int st = kStages[k](c, s);
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (st != COX_OK || e != hipSuccess || !g) {
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
+      I->use_graphs = false;  // capture not possible here: stay eager from now on
+      return kStages[k](c, s);
+    }
+    const hipError_t ei = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) {
+      gx = nullptr;
+      (void)hipGetLastError();
+      I->use_graphs = false;
+      return kStages[k](c, s);
+    }
+  }
+  COX_HIP(hipGraphLaunch(gx, s));
+  return COX_OK;
 }
 
 // enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
 static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
   cox_layer* Lh = I->layer;
   COX_TRY(ensure_capacity(I, n));
-  FrameParams P = make_params(I, T, n, freespace);
-  P.frame_id = ++Lh->frame_id;
-  LayerView L{Lh->voxels, Lh->ht_keys, Lh->ht_vals, Lh->ht_stamp, Lh->ht_ord, Lh->block_keys, Lh->d_nblocks, Lh->ht_cap - 1, static_cast<u32>(Lh->capacity)};
-  I->frame_no += 1;
-  FrameSet& F = I->fs[I->frame_no % kFrameSets];
-  BundleSet& B = I->bs[I->frame_no & 1u];
-  RecordSet& S = I->rs[I->frame_no & 1u];
-  hipStream_t s_a1 = I->st[0], s_a2 = I->st[1], s_b1 = I->st[2], s_b2 = I->st[3];
-  RayArrays R = F.rays;
-  Counters* C = F.cnt;
   I->last = cox_frame_stats{};
   I->last.n_points = n;
   I->last_has_counts = false;
   if (n == 0) return COX_OK;
-  refresh_hints(I);
-  const u32 fh_mask = I->fh_cap - 1;
-  const bool merged = I->method == COX_METHOD_MERGED;
-  u32 ray_hint = n;
+  I->frame_no += 1;
+  const int slot = static_cast<int>(I->frame_no % kFrameSets);
+  FrameSet& F = I->fs[slot];
+  BundleSet& B = I->bs[slot & 1];
+  RecordSet& S = I->rs[slot & 1];
+  const StageCtx ctx{I, &F, &B, &S, slot};
+  // the pinned parameter slot is free once the copy of the frame that used it last (t-4) has run
+  if (F.used) COX_HIP(hipEventSynchronize(F.params_copied));
+  FrameParams P = make_params(I, T, n, freespace, xyz, rgba);
+  P.frame_id = ++Lh->frame_id;
+  I->h_params[slot] = P;
 
-  // ---------------- stage A1: bundle hash + bundling sort (input only) ----------------
-  if (F.used) COX_HIP(hipStreamWaitEvent(s_a1, F.done, 0));  // frame t-4 is done with this frame set
-  if (B.used) COX_HIP(hipStreamWaitEvent(s_a1, B.done, 0));  // frame t-2's A2 is done with this bundle set
-  COX_HIP(hipMemsetAsync(C, 0, sizeof(Counters), s_a1));
-  u32 np2 = 0;
-  const u32 *sk = nullptr, *sv = nullptr;
-  if (merged) {
-    np2 = next_pow2(static_cast<u64>(n) + 1);
-    COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s_a1));
-    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s_a1, P, xyz, F.fh_keys, F.fh_first, fh_mask, B.pslot, C);
-    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s_a1, n, np2, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0]);
-    const int kbits = ceil_log2(np2) + 1;  // + clearing bit; kInvalid's low bits exceed every valid key
-    const int cur = radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], nullptr, n, n, kbits, false, 0, I->sort_pts, nullptr, s_a1);
-    sk = B.skey[cur];
-    sv = B.sval[cur];
+  // A1
+  if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-4 is done with this frame set
+  if (B.used && I->st[1] != I->st[0]) COX_HIP(hipStreamWaitEvent(I->st[0], B.done, 0));  // frame t-2's A2 is done with this bundle set
+  COX_TRY(run_stage(0, ctx));
+  COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
+  // A2
+  if (I->st[1] != I->st[0]) {
+    COX_HIP(hipEventRecord(I->ev_a1, I->st[0]));
+    COX_HIP(hipStreamWaitEvent(I->st[1], I->ev_a1, 0));
   }
-  COX_HIP(hipEventRecord(I->ev_a1, s_a1));
-
-  // ---------------- stage A2: bundle boundaries + sequential means -> rays ----------------
-  COX_HIP(hipStreamWaitEvent(s_a2, I->ev_a1, 0));
-  if (merged) {
-    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, s_a2, n, sk, B.head);
-    // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
-    exclusive_scan_u32(B.head, B.head, nullptr, n, n, &C->n_rays, I->scanws_a, s_a2);
-    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s_a2, n, sk, B.head, B.bstart, C);
-    ray_hint = I->hint_rays ? std::min(I->hint_rays, n) : std::min<u32>(n, 16384);
-    hipEvent_t m0 = nullptr, m1 = nullptr;
-    if (I->profiling) {
-      COX_HIP(hipEventCreate(&m0));
-      COX_HIP(hipEventCreate(&m1));
-      COX_HIP(hipEventRecord(m0, s_a2));
-    }
-    hipLaunchKernelGGL(k_bundle_merge, grid_for(ray_hint * 128u, 256, 8192), dim3(256), 0, s_a2, P, np2, xyz, rgba, sk, sv, B.bstart, R, C);
-    if (I->profiling) {
-      COX_HIP(hipEventRecord(m1, s_a2));
-      I->merge_events.emplace_back(m0, m1);
-    }
-  } else {
-    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s_a2, P, xyz, rgba, R, C);
-  }
-  COX_HIP(hipEventRecord(I->ev_a2, s_a2));
-  COX_HIP(hipEventRecord(B.done, s_a2));
+  COX_TRY(run_stage(1, ctx));
+  COX_HIP(hipEventRecord(I->ev_a2, I->st[1]));
+  COX_HIP(hipEventRecord(B.done, I->st[1]));
   B.used = true;
-
-  // ---------------- stage B1: record offsets, block allocation, records, record sort ----------------
-  COX_HIP(hipStreamWaitEvent(s_b1, I->ev_a2, 0));
-  if (S.used) COX_HIP(hipStreamWaitEvent(s_b1, S.done, 0));  // frame t-2's B2 is done with this record set
-  exclusive_scan_u32(R.nsteps, R.rec_off, &C->n_ray_slots, n, ray_hint, &C->n_records, I->scanws_b, s_b1);
-  if (merged) {
-    // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
-    hipLaunchKernelGGL(k_touch_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s_b1, P, R, L, S.touched_slots, S.rec_key[1], I->rcap, C, Lh->d_err,
-                       F.fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit_wave, grid_for(ray_hint * 64u, 256, 4096), dim3(256), 0, s_b1, P, R, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, C,
-                       S.sort_info, F.fh_keys, fh_mask);
-  } else {
-    hipLaunchKernelGGL(k_touch, grid_for(ray_hint, 256, 8192), dim3(256), 0, s_b1, P, R, L, S.touched_slots, C, Lh->d_err, F.fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit, grid_for(ray_hint, 256, 8192), dim3(256), 0, s_b1, P, R, L, S.rec_key[0], S.rec_ray[0], I->rcap, C, S.sort_info, F.fh_keys,
-                       fh_mask);
+  // B1
+  COX_HIP(hipStreamWaitEvent(I->st[2], I->ev_a2, 0));
+  if (S.used && I->st[3] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[2], S.done, 0));  // frame t-2's B2 is done with this record set
+  COX_TRY(run_stage(2, ctx));
+  // B2
+  if (I->st[3] != I->st[2]) {
+    COX_HIP(hipEventRecord(I->ev_b1, I->st[2]));
+    COX_HIP(hipStreamWaitEvent(I->st[3], I->ev_b1, 0));
   }
-  const u32 rec_hint = I->hint_records ? std::min(I->hint_records, I->rcap) : std::min<u32>(I->rcap, std::max<u32>(1u << 20, n * 4u));
-  // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits
-  (void)radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &C->n_records, I->rcap, rec_hint, 0, true, 3, I->sort_rec, S.sort_info,
-                             s_b1);
-  COX_HIP(hipEventRecord(I->ev_b1, s_b1));
-
-  // ---------------- stage B2: apply ----------------
-  COX_HIP(hipStreamWaitEvent(s_b2, I->ev_b1, 0));
-  RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &C->n_records};
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (I->profiling) {
-    COX_HIP(hipEventCreate(&e0));
-    COX_HIP(hipEventCreate(&e1));
-    COX_HIP(hipEventRecord(e0, s_b2));
-  }
-  hipLaunchKernelGGL(k_apply_eval, grid_for(rec_hint, 256, 16384), dim3(256), 0, s_b2, P, R, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, C);
-  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s_b2, P, R, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, C, Lh->d_err);
-  if (I->profiling) {
-    COX_HIP(hipEventRecord(e1, s_b2));
-    I->apply_events.emplace_back(e0, e1);
-  }
-  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], C, sizeof(Counters), hipMemcpyDeviceToHost, s_b2));
-  COX_HIP(hipEventRecord(F.done, s_b2));
-  COX_HIP(hipEventRecord(S.done, s_b2));
+  COX_TRY(run_stage(3, ctx));
+  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], F.cnt, sizeof(Counters), hipMemcpyDeviceToHost, I->st[3]));
+  COX_HIP(hipEventRecord(F.done, I->st[3]));
+  COX_HIP(hipEventRecord(S.done, I->st[3]));
   F.used = true;
   S.used = true;
-  I->counts_frame = I->frame_no;
   I->last_has_counts = true;
   COX_HIP(hipGetLastError());
   return COX_OK;
@@ -1393,7 +1515,6 @@ static void fold_counters(cox_integrator* I) {
   I->last.n_touched_voxels = c.n_voxels;
   I->last.n_touched_blocks = c.n_touched;
   I->last.n_new_blocks = c.n_new_blocks;
-  if (c.n_records) I->hint_records = std::max<u32>(I->hint_records, c.n_records + c.n_records / 4 + 65536);
 }
 
 static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc) {
@@ -1436,31 +1557,52 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   I->layer = layer;
   I->cfg = *cfg;
   I->method = method;
+  // stage graphs: measured slightly slower than eager launches here (2 936 vs 3 117 frames/s), so opt-in
+  I->use_graphs = std::getenv("COX_GRAPH") != nullptr && std::getenv("COX_NO_GRAPH") == nullptr;
   int st = COX_OK;
   auto ev = [&](hipEvent_t* e) {
     if (st == COX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
   };
-  for (int k = 0; k < 4; ++k)
-    if (st == COX_OK && hipStreamCreateWithFlags(&I->st[k], hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  // The hardware runs at most two of these kernels side by side (measured: profiles/), so two
+  // streams (ray generation | layer update) give all the overlap there is; COX_STREAMS=4 puts every stage on its own.
+  I->n_streams = (std::getenv("COX_STREAMS") && std::atoi(std::getenv("COX_STREAMS")) == 4) ? 4 : 2;
+  for (int k = 0; k < 4; ++k) {
+    if (I->n_streams == 2 && (k & 1)) {
+      I->st[k] = I->st[k - 1];
+    } else if (st == COX_OK && hipStreamCreateWithFlags(&I->st[k], hipStreamNonBlocking) != hipSuccess) {
+      st = COX_ERR_NO_DEVICE;
+    }
+  }
   ev(&I->ev_a1);
   ev(&I->ev_a2);
   ev(&I->ev_b1);
   for (FrameSet& F : I->fs) {
     ev(&F.done);
+    ev(&F.params_copied);
     if (st == COX_OK) st = dev_realloc(&F.cnt, 1);
+    if (st == COX_OK) st = dev_realloc(&F.d_params, 1);
   }
-  for (BundleSet& B : I->bs) ev(&B.done);
+  auto info = [&](SortInfo** p) {
+    if (st == COX_OK) st = dev_realloc(p, 1);
+    if (st == COX_OK && hipMemset(*p, 0, sizeof(SortInfo)) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  };
+  for (BundleSet& B : I->bs) {
+    ev(&B.done);
+    info(&B.sort_info);
+  }
   for (RecordSet& S : I->rs) {
     ev(&S.done);
     if (st == COX_OK) st = dev_realloc(&S.touched_slots, layer->ht_cap);  // one entry per block key the table can hold
-    if (st == COX_OK) st = dev_realloc(&S.sort_info, 1);
-    if (st == COX_OK && hipMemset(S.sort_info, 0, sizeof(SortInfo)) != hipSuccess) st = COX_ERR_NO_DEVICE;
+    info(&S.sort_info);
   }
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
+    st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_params), sizeof(FrameParams) * kFrameSets, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK) st = dev_realloc(&I->d_depth_n, 1);
   if (st == COX_OK) {
     memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
+    memset(I->h_params, 0, sizeof(FrameParams) * kFrameSets);
     st = ensure_capacity(I, 640 * 480);
   }
   if (st != COX_OK) {
@@ -1475,6 +1617,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   if (!I) return;
   (void)hipSetDevice(I->layer->device);
   (void)sync_all(I);
+  drop_graphs(I);
   for (auto* evs : {&I->apply_events, &I->merge_events})
     for (auto& e : *evs) {
       (void)hipEventDestroy(e.first);
@@ -1487,13 +1630,14 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     const RayArrays& R = F.rays;
     for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
                     static_cast<void*>(R.flags), static_cast<void*>(R.key), static_cast<void*>(R.nsteps), static_cast<void*>(R.rec_off),
-                    static_cast<void*>(F.fh_keys), static_cast<void*>(F.cnt)})
+                    static_cast<void*>(F.fh_keys), static_cast<void*>(F.cnt), static_cast<void*>(F.d_params)})
       ptrs.push_back(p);
     events.push_back(F.done);
+    events.push_back(F.params_copied);
   }
   for (BundleSet& B : I->bs) {
     for (void* p : {static_cast<void*>(B.pslot), static_cast<void*>(B.skey[0]), static_cast<void*>(B.skey[1]), static_cast<void*>(B.sval[0]),
-                    static_cast<void*>(B.sval[1]), static_cast<void*>(B.head), static_cast<void*>(B.bstart)})
+                    static_cast<void*>(B.sval[1]), static_cast<void*>(B.head), static_cast<void*>(B.bstart), static_cast<void*>(B.sort_info)})
       ptrs.push_back(p);
     events.push_back(B.done);
   }
@@ -1509,8 +1653,9 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
+  if (I->h_params) (void)hipHostFree(I->h_params);
   for (int k = 0; k < 4; ++k)
-    if (I->st[k]) (void)hipStreamDestroy(I->st[k]);
+    if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
   delete I;
 }
 
@@ -1530,7 +1675,6 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   if (n) {
     COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st[0]));
     if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->st[0]));
-    if (I->method != COX_METHOD_MERGED) COX_HIP(hipStreamSynchronize(I->st[0]));  // simple: the first consumer runs on the A2 stream after an empty A1
   }
   COX_TRY(integrate_device(I, T_G_C, I->own_xyz, rgba ? I->own_rgba : nullptr, static_cast<u32>(n), freespace));
   return integrator_finish(I);

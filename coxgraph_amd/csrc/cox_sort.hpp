@@ -190,16 +190,21 @@ __global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restr
   const u32 chunk = (n_tiles + kWaves - 1) / kWaves;
   const u32 t_begin = min(n_tiles, wave * chunk), t_end = min(n_tiles, t_begin + chunk);
   u32 sum = 0;
+#pragma unroll 4
   for (u32 t = t_begin; t < t_end; ++t) sum += counts[static_cast<size_t>(t) * kDigits + d0 + lane];
   part[wave][lane] = sum;
   __syncthreads();
   u32 run = group_base + digit_excl;
   for (u32 w = 0; w < wave; ++w) run += part[w][lane];
-  for (u32 t = t_begin; t < t_end; ++t) {
-    u32* p = counts + static_cast<size_t>(t) * kDigits + d0 + lane;
-    const u32 v = *p;
-    *p = run;
-    run += v;
+  for (u32 t = t_begin; t < t_end; t += 4) {  // 4 independent loads in flight per step
+    u32 v[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) v[q] = (t + q < t_end) ? counts[static_cast<size_t>(t + q) * kDigits + d0 + lane] : 0u;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      if (t + q < t_end) counts[static_cast<size_t>(t + q) * kDigits + d0 + lane] = run;
+      run += v[q];
+    }
   }
   if (host_bits < 0 && blockIdx.x == 0 && threadIdx.x == 0) info->parity = (pass + 1) & 1;  // this pass runs: its output buffer is current
 }
