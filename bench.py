@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--reg-iters", type=int, default=50)
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="sync after every frame (profiling aid: kernel times without cross-frame overlap)")
     return ap.parse_args()
 
 
@@ -106,6 +107,8 @@ def main():
     def step(i):
         T, xyz, rgba, n = dev_frames[i]
         integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+        if args.serial:
+            integ.sync()
 
     for i in range(args.warmup):
         step(i)

@@ -45,8 +45,13 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_new_blocks;
   u32 err;
   u32 n_depth_points;
-  u32 pad;
+  u32 n_sorted_valid;  // valid points as seen in the sorted bundling keys (merged)
+  // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
+  // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
+  // [s][0] valid points, [s][1] updates, [s][2] voxels, [s][3] long runs, [s][4] rays
+  u32 shard[64][16];
 };
+enum : u32 { kShValid = 0, kShUpdates = 1, kShVoxels = 2, kShLong = 3, kShRays = 4 };
 
 struct LayerView {
   u32* voxels;
@@ -135,16 +140,16 @@ __global__ void __launch_bounds__(256) k_rays_simple(const FrameParams* __restri
   R.nsteps[seq] = nsteps;
   const u64 m = __ballot(valid);
   if (lane_id() == 0 && m) {
-    atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
-    atomicAdd(&cnt->n_rays, static_cast<u32>(__popcll(m)));
+    u32* sh = cnt->shard[(seq >> 6) & 63u];
+    atomicAdd(&sh[kShValid], static_cast<u32>(__popcll(m)));
+    atomicAdd(&sh[kShRays], static_cast<u32>(__popcll(m)));
   }
 }
 
 // ---- merged: bundle points by terminal voxel ---------------------------------------------------
 // thread = point (so neighbouring lanes are neighbouring pixels and mostly share a terminal voxel): the lanes of a
 // wave that hold the same key elect one leader, which inserts the key in the per-frame hash once and records the
-// smallest sequence number of the group as a candidate for the bundle's first visit.  pslot is indexed by the
-// point's "mixed" sequence number, the order the bundling sort must start from.
+// smallest sequence number of the group as a candidate for the bundle's first visit.
 __global__ void __launch_bounds__(256) k_bundle_insert(const FrameParams* __restrict__ Pp, u64* __restrict__ fh_keys, u32* __restrict__ fh_first,
                                                        u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
   const FrameParams P = *Pp;
@@ -200,9 +205,9 @@ __global__ void __launch_bounds__(256) k_bundle_insert(const FrameParams* __rest
   }
   const u32 got = static_cast<u32>(__shfl(static_cast<int>(sl), static_cast<int>(my_leader), 64));
   const u32 slot = valid ? got : kInvalid;
-  if (idx < P.n_points) pslot[seq] = slot;  // kInvalid for points that are not integrated
+  if (idx < P.n_points) pslot[idx] = slot;  // kInvalid for points that are not integrated; indexed by point (coalesced)
   const u64 m = __ballot(valid && slot != kInvalid);
-  if (lane == 0 && m) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(m)));
+  if (lane == 0 && m) atomicAdd(&cnt->shard[(idx >> 6) & 63u][kShValid], static_cast<u32>(__popcll(m)));
 }
 // sort key of a point = (clearing ? np2 : 0) + first sequence number of its bundle; value = seq.  Also publishes the
 // key width of the bundling sort.
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(256) k_bundle_keys(const FrameParams* __restri
     sort_info->parity = 0;
   }
   if (seq >= n) return;
-  const u32 slot = pslot[seq];
+  const u32 slot = pslot[mixed_index(seq, n)];  // the bundling sort starts from visiting order: gather on the read side
   u32 k = kInvalid;
   if (slot != kInvalid) k = fh_first[slot] + ((fh_keys[slot] >> 63) ? np2 : 0u);
   skey[seq] = k;
@@ -246,6 +251,7 @@ __global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __rest
   const u32* __restrict__ skey = V.key[V.info->parity & 1u];
   const u32 k = skey[i];
   if (k != kInvalid && (i == 0 || skey[i - 1] != k)) bstart[head_scan[i]] = i;
+  if (k != kInvalid && (i + 1 == n || skey[i + 1] == kInvalid)) cnt->n_sorted_valid = i + 1;  // invalid keys sort last: one writer
 }
 
 // two waves per bundle: the sequential weighted mean of its points in visiting order, bit-exact with the
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
   const u32* __restrict__ sval = V.val[spar];
   __shared__ MergeOp ops[4][64][4];
   const u32 n_bundles = uniform_u32(cnt->n_rays);
-  const u32 n_valid = uniform_u32(cnt->n_valid);
+  const u32 n_valid = uniform_u32(cnt->n_sorted_valid);
   const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nthreads = gridDim.x * blockDim.x;
   const u32 lane = lane_id();
@@ -965,9 +971,10 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (blk_updates) atomicAdd(&cnt->n_updates, blk_updates);
-    if (blk_voxels) atomicAdd(&cnt->n_voxels, blk_voxels);
-    if (blk_long) atomicAdd(&cnt->n_long, blk_long);
+    u32* sh = cnt->shard[blockIdx.x & 63u];
+    if (blk_updates) atomicAdd(&sh[kShUpdates], blk_updates);
+    if (blk_voxels) atomicAdd(&sh[kShVoxels], blk_voxels);
+    if (blk_long) atomicAdd(&sh[kShLong], blk_long);
   }
 }
 
@@ -1001,7 +1008,7 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
   // last kernel of the frame: make this frame's error bits sticky until the host next looks
   if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
   const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
-  if (n == 0 || uniform_u32(cnt->n_long) == 0) return;
+  if (n == 0) return;
   const u32 par = uniform_u32(V.info->parity & 1u);
   const u32* __restrict__ rec_key = V.key[par];
   const u32* __restrict__ rec_ray = V.ray[par];
@@ -1372,6 +1379,32 @@ static int stage_a2(const StageCtx& c, hipStream_t s) {
   }
   return COX_OK;
 }
+// exclusive scan of at most a few thousand ray step counts in ONE launch (the three-launch scan is latency-bound there)
+__global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ d_n, u32 n_max,
+                                                     u32* __restrict__ d_total) {
+  __shared__ u32 lds[16];
+  const u32 n = min(*d_n, n_max);
+  u32 carry = 0;
+  for (u32 base = 0; base < n; base += 1024 * 4) {
+    const u32 i0 = base + threadIdx.x * 4;
+    u32 v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = (i0 + q < n) ? in[i0 + q] : 0u;
+      sum += v[q];
+    }
+    u32 total;
+    u32 ex = carry + block_exclusive_scan<16>(sum, &total, lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i0 + q < n) out[i0 + q] = ex;
+      ex += v[q];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0) *d_total = carry;
+}
+
 static int stage_b1(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
@@ -1379,8 +1412,10 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   const u32 fh_mask = I->fh_cap - 1;
   const bool merged = I->method == COX_METHOD_MERGED;
-  exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, merged ? std::min<u32>(I->pcap, 32768) : I->pcap, &F.cnt->n_records,
-                     I->scanws_b, s);
+  if (merged)  // a few thousand bundles: one launch
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, &F.cnt->n_records);
+  else
+    exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_records, I->scanws_b, s);
   if (merged) {
     // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
     hipLaunchKernelGGL(k_touch_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt, I->layer->d_err, F.fh_keys,
@@ -1509,10 +1544,13 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
 static void fold_counters(cox_integrator* I) {
   if (!I->last_has_counts) return;
   const Counters& c = I->h_ring[I->frame_no % kStatRing];
-  I->last.n_valid = c.n_valid;
-  I->last.n_rays = c.n_rays;
-  I->last.n_updates = c.n_updates;
-  I->last.n_touched_voxels = c.n_voxels;
+  u64 sh[5] = {0, 0, 0, 0, 0};
+  for (int s = 0; s < 64; ++s)
+    for (int k = 0; k < 5; ++k) sh[k] += c.shard[s][k];
+  I->last.n_valid = sh[kShValid];
+  I->last.n_rays = (I->method == COX_METHOD_MERGED) ? c.n_rays : sh[kShRays];
+  I->last.n_updates = sh[kShUpdates];
+  I->last.n_touched_voxels = sh[kShVoxels];
   I->last.n_touched_blocks = c.n_touched;
   I->last.n_new_blocks = c.n_new_blocks;
 }
