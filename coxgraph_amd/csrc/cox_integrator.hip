@@ -343,17 +343,20 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
       }
       const float den = Wpre + w;
       const float Wnext = used ? den : Wpre;
+      const bool d_ok = !used || (den >= 9.094947e-13f && den <= 1.0995116e12f);  // divisor range of the fast division
       // operand table of this chunk
       if (lane < cnt_in) {
         MergeOp* row = tbl[lane];
-        const MergeOp ident{1.0f, 0.0f, 1.0f, 0.0f};
+        const MergeOp ident{1.0f, 0.0f, 1.0f, 1.0f};
         if (!used) {
 #pragma unroll
           for (u32 c = 0; c < 4; ++c) row[c] = ident;
         } else if (!colour_wave) {
-          row[0] = MergeOp{Wpre, px * w, den, 0.0f};
-          row[1] = MergeOp{Wpre, py * w, den, 0.0f};
-          row[2] = MergeOp{Wpre, pz * w, den, 0.0f};
+          const float r0 = __builtin_amdgcn_rcpf(den);
+          const float r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);  // one Newton step: < 1 ulp from 1/den
+          row[0] = MergeOp{Wpre, px * w, den, r};
+          row[1] = MergeOp{Wpre, py * w, den, r};
+          row[2] = MergeOp{Wpre, pz * w, den, r};
           row[3] = ident;
         } else {
           const float fa = Wpre / den, fb = w / den;  // colour blend factors of this point
@@ -365,10 +368,34 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
       // the dependent chain
       MergeOp nxt = tbl[0][role];
       if (!colour_wave) {
+        // IEEE division with everything that depends only on the divisor hoisted off the chain: r = refined 1/D sits in
+        // the table; q0 = N r, then two residual corrections -- the same Newton sequence the compiler emits for '/',
+        // minus its range scaling.  A correctly rounded quotient is unique, so the bits equal the oracle's '/' whenever
+        // no intermediate can leave the normal range; |N| and |D| are tracked off the critical path and the chunk is
+        // redone with plain '/' if they ever left [2^-40, 2^40] (or N was 0, where the sign of zero would differ).
+        const float val_in = val;
+        float n_lo = 1.0f, n_hi = 1.0f;
         for (u32 k = 0; k < cnt_in; ++k) {
           const MergeOp op = nxt;
           nxt = tbl[(k + 1) & 63u][role];  // prefetch: the operands do not depend on the chain
-          val = (val * op.x + op.y) / op.z;
+          const float N = val * op.x + op.y;
+          n_lo = fminf(n_lo, fabsf(N));
+          n_hi = fmaxf(n_hi, fabsf(N));
+          const float q0 = N * op.w;
+          const float e0 = __builtin_fmaf(-op.z, q0, N);
+          const float q1 = __builtin_fmaf(e0, op.w, q0);
+          const float e1 = __builtin_fmaf(-op.z, q1, N);
+          val = __builtin_fmaf(e1, op.w, q1);
+        }
+        const bool bad = (lane < 3) && !(n_lo >= 9.094947e-13f && n_hi <= 1.0995116e12f);  // NaN fails too
+        if (__ballot(bad || !d_ok)) {
+          val = val_in;
+          nxt = tbl[0][role];
+          for (u32 k = 0; k < cnt_in; ++k) {
+            const MergeOp op = nxt;
+            nxt = tbl[(k + 1) & 63u][role];
+            val = (val * op.x + op.y) / op.z;
+          }
         }
       } else {
         for (u32 k = 0; k < cnt_in; ++k) {
@@ -1096,6 +1123,36 @@ __global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ 
   if (rgba_out) reinterpret_cast<u32*>(rgba_out)[o] = rgba ? reinterpret_cast<const u32*>(rgba)[i] : 0u;
 }
 
+// ---- self-test: the hoisted-reciprocal division of k_bundle_merge against the compiler's IEEE '/' -----------------
+__global__ void __launch_bounds__(256) k_selftest_division(u64 n, u64 seed, u32* __restrict__ mismatches) {
+  u64 bad = 0;
+  for (u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x; i < n; i += static_cast<u64>(gridDim.x) * blockDim.x) {
+    // splitmix64 -> two floats: divisor like the merge's (small integers and arbitrary values in 2^-40..2^40), arbitrary numerator
+    u64 z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const u32 a = static_cast<u32>(z), b = static_cast<u32>(z >> 32);
+    float D, N;
+    if ((i & 3) == 0) {
+      D = static_cast<float>((b % 200000u) + 1u);  // W + w with unit weights
+    } else {
+      D = __uint_as_float(((b & 0x007FFFFFu) | (((b >> 23) % 80u + 87u) << 23)));  // exponent -40..39
+    }
+    N = __uint_as_float((a & 0x807FFFFFu) | ((((a >> 23) & 0xFFu) % 80u + 87u) << 23));
+    const float r0 = __builtin_amdgcn_rcpf(D);
+    const float r = __builtin_fmaf(__builtin_fmaf(-D, r0, 1.0f), r0, r0);
+    const float q0 = N * r;
+    const float e0 = __builtin_fmaf(-D, q0, N);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-D, q1, N);
+    const float q = __builtin_fmaf(e1, r, q1);
+    const float ref = N / D;
+    if (__float_as_uint(q) != __float_as_uint(ref)) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, static_cast<u32>(bad > 0xFFFFFFFFull ? 0xFFFFFFFFull : bad));
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -1774,6 +1831,23 @@ int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* 
     I->apply_launches = 0;
   }
   return st;
+}
+
+int cox_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t* mismatches) {
+  COX_ENTRY();
+  if (!mismatches) return COX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return COX_ERR_NO_DEVICE;
+  COX_HIP(hipSetDevice(device));
+  u32* d = nullptr;
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(u32)));
+  COX_HIP(hipMemset(d, 0, sizeof(u32)));
+  hipLaunchKernelGGL(k_selftest_division, dim3(4096), dim3(256), 0, nullptr, n, seed, d);
+  u32 h = 0;
+  COX_HIP(hipMemcpy(&h, d, sizeof(u32), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *mismatches = h;
+  return COX_OK;
 }
 
 int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launches[2], int reset) {

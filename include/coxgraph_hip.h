@@ -145,6 +145,11 @@ int cox_integrator_kernel_time(cox_integrator_t* integ, double* apply_ms, uint64
  * frame), [1] = the TSDF update stage (k_apply_eval + k_apply_long) */
 int cox_integrator_stage_times(cox_integrator_t* integ, double ms[2], uint64_t launches[2], int reset);
 
+/* self-test: the merged integrator evaluates its sequential mean with an IEEE division whose divisor-only part is
+ * hoisted out of the dependent chain; this compares it bit for bit with the compiler's '/' on n pseudo-random operand
+ * pairs in the range the kernel accepts and returns the number of differing results (must be 0) */
+int cox_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t* mismatches);
+
 /* ---- registration (voxgraph RegistrationCostFunction) ------------------------------------- */
 typedef struct cox_reg_config {
   double no_correspondence_cost; /* voxgraph registration.no_correspondence_cost, default 0 */

@@ -234,3 +234,12 @@ def test_one_centimetre_voxels(hip, oracle):
     rep = compare_layers(la, lb)
     print(rep, sa[-1])
     assert rep["bitexact_d"] and rep["bitexact_w"]
+
+
+def test_hoisted_reciprocal_division_is_correctly_rounded(hip):
+    """k_bundle_merge's division (reciprocal refined off the dependent chain) must equal IEEE '/' bit for bit."""
+    import ctypes as C
+    bad = C.c_uint64(123)
+    for seed in (1, 2, 3):
+        hip.check(hip.fn("selftest_division")(C.c_int(0), C.c_uint64(1 << 28), C.c_uint64(seed), C.byref(bad)), "selftest_division")
+        assert bad.value == 0, bad.value
