@@ -344,8 +344,8 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
       const float den = Wpre + w;
       const float Wnext = used ? den : Wpre;
       const bool d_ok = !used || (den >= 9.094947e-13f && den <= 1.0995116e12f);  // divisor range of the fast division
-      // operand table of this chunk
-      if (lane < cnt_in) {
+      // operand table of this chunk; rows beyond the chunk are the identity so the chain can run in groups of 4
+      {
         MergeOp* row = tbl[lane];
         const MergeOp ident{1.0f, 0.0f, 1.0f, 1.0f};
         if (!used) {
@@ -375,17 +375,32 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
         // redone with plain '/' if they ever left [2^-40, 2^40] (or N was 0, where the sign of zero would differ).
         const float val_in = val;
         float n_lo = 1.0f, n_hi = 1.0f;
-        for (u32 k = 0; k < cnt_in; ++k) {
-          const MergeOp op = nxt;
-          nxt = tbl[(k + 1) & 63u][role];  // prefetch: the operands do not depend on the chain
-          const float N = val * op.x + op.y;
-          n_lo = fminf(n_lo, fabsf(N));
-          n_hi = fmaxf(n_hi, fabsf(N));
-          const float q0 = N * op.w;
-          const float e0 = __builtin_fmaf(-op.z, q0, N);
-          const float q1 = __builtin_fmaf(e0, op.w, q0);
-          const float e1 = __builtin_fmaf(-op.z, q1, N);
-          val = __builtin_fmaf(e1, op.w, q1);
+        // groups of 4 steps with the next group's operands already in flight: the LDS latency (~100 cycles) would
+        // otherwise bound every step of the chain
+        MergeOp a0 = tbl[0][role], a1 = tbl[1][role], a2 = tbl[2][role], a3 = tbl[3][role];
+        for (u32 k = 0; k < cnt_in; k += 4) {
+          const MergeOp o0 = a0, o1 = a1, o2 = a2, o3 = a3;
+          const u32 kn = (k + 4) & 63u;
+          a0 = tbl[kn][role];
+          a1 = tbl[kn + 1][role];
+          a2 = tbl[kn + 2][role];
+          a3 = tbl[kn + 3][role];
+#define COX_MERGE_STEP(op)                                  \
+  {                                                         \
+    const float N = val * (op).x + (op).y;                  \
+    n_lo = fminf(n_lo, fabsf(N));                           \
+    n_hi = fmaxf(n_hi, fabsf(N));                           \
+    const float q0 = N * (op).w;                            \
+    const float e0 = __builtin_fmaf(-(op).z, q0, N);        \
+    const float q1 = __builtin_fmaf(e0, (op).w, q0);        \
+    const float e1 = __builtin_fmaf(-(op).z, q1, N);        \
+    val = __builtin_fmaf(e1, (op).w, q1);                   \
+  }
+          COX_MERGE_STEP(o0)
+          COX_MERGE_STEP(o1)
+          COX_MERGE_STEP(o2)
+          COX_MERGE_STEP(o3)
+#undef COX_MERGE_STEP
         }
         const bool bad = (lane < 3) && !(n_lo >= 9.094947e-13f && n_hi <= 1.0995116e12f);  // NaN fails too
         if (__ballot(bad || !d_ok)) {
@@ -398,10 +413,18 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
           }
         }
       } else {
-        for (u32 k = 0; k < cnt_in; ++k) {
-          const MergeOp op = nxt;
-          nxt = tbl[(k + 1) & 63u][role];
-          val = roundf(val * op.x + op.y);
+        MergeOp a0 = tbl[0][role], a1 = tbl[1][role], a2 = tbl[2][role], a3 = tbl[3][role];
+        for (u32 k = 0; k < cnt_in; k += 4) {
+          const MergeOp o0 = a0, o1 = a1, o2 = a2, o3 = a3;
+          const u32 kn = (k + 4) & 63u;
+          a0 = tbl[kn][role];
+          a1 = tbl[kn + 1][role];
+          a2 = tbl[kn + 2][role];
+          a3 = tbl[kn + 3][role];
+          val = roundf(val * o0.x + o0.y);
+          val = roundf(val * o1.x + o1.y);
+          val = roundf(val * o2.x + o2.y);
+          val = roundf(val * o3.x + o3.y);
         }
       }
       wave_lds_handover();
