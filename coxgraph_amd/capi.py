@@ -132,6 +132,17 @@ class Layer:
             self.eng.check(f(self.h, _fp(idx), _fp(vox), C.c_uint64(nb), C.byref(n)), "layer_download")
         return idx, vox
 
+    def registration_points(self, min_voxel_weight=1.0, max_voxel_distance=0.3):
+        """finishSubmap()'s relevant voxels: float32 [n,5] = x, y, z, distance, weight."""
+        n = C.c_uint64()
+        f = self.eng.fn("layer_registration_points")
+        self.eng.check(f(self.h, C.c_float(min_voxel_weight), C.c_float(max_voxel_distance), None, C.c_uint64(0), C.byref(n)), "layer_registration_points")
+        out = np.zeros((int(n.value), 5), np.float32)
+        if n.value:
+            self.eng.check(f(self.h, C.c_float(min_voxel_weight), C.c_float(max_voxel_distance), _fp(out), C.c_uint64(n.value), C.byref(n)),
+                           "layer_registration_points")
+        return out
+
     def upload(self, idx, vox, action=0):
         idx = np.ascontiguousarray(idx, np.int32)
         vox = np.ascontiguousarray(vox, np.uint32)
@@ -215,6 +226,19 @@ class RegPoints:
         self.n = pts.shape[0]
         self.h = C.c_void_p()
         eng.check(eng.fn("regpoints_create")(C.c_int(device), _fp(pts), C.c_uint64(self.n), C.byref(self.h)), "regpoints_create")
+
+    @classmethod
+    def from_layer(cls, eng, layer, min_voxel_weight=1.0, max_voxel_distance=0.3):
+        """finishSubmap()'s relevant-voxel set, built and kept on the engine's side (no host round trip)."""
+        self = cls.__new__(cls)
+        self.eng = eng
+        self.h = C.c_void_p()
+        eng.check(eng.fn("regpoints_from_layer")(layer.h, C.c_float(min_voxel_weight), C.c_float(max_voxel_distance), C.byref(self.h)),
+                  "regpoints_from_layer")
+        n = C.c_uint64()
+        eng.check(eng.fn("regpoints_size")(self.h, C.byref(n)), "regpoints_size")
+        self.n = int(n.value)
+        return self
 
     def close(self):
         if self.h:

@@ -56,6 +56,13 @@ struct cox_layer {
   u32 frame_id = 0;           // shared by every integrator on this layer
 };
 
+// voxgraph registration point set of a submap, resident on one GPU
+struct cox_regpoints {
+  int device = 0;
+  float* pts = nullptr;  // n * {x, y, z, distance, weight}
+  u64 n = 0;
+};
+
 // hipGetLastError() is a per-thread sticky slot shared with every other HIP user in the process
 // (PyTorch probes peers / devices during its lazy init and may leave a benign error behind).  Every
 // entry point clears it first so that the check after our own launches only sees our own errors.

@@ -315,3 +315,145 @@ extern "C" int cox_layer_upload(cox_layer_t* L, const int32_t* block_idx_xyz, co
   return err_bits_to_status(err);
 }
 
+
+// =================================================================================================
+// registration points of a finished submap ("voxels" / implicit_to_implicit set)
+// =================================================================================================
+// VoxgraphSubmap::finishSubmap() (called when a submap arrives, coxgraph/include/coxgraph/utils/msg_converter.h:113)
+// -> findRelevantVoxelIndices: every voxel with weight > min_voxel_weight and |distance| < max_voxel_distance becomes a
+// RegistrationPoint{position = voxel centre (Block::computeCoordinatesFromLinearIndex), distance, weight}.
+// Order here: blocks by (z, y, x), voxels by linear index -- deterministic (upstream iterates a hash map).
+__device__ __forceinline__ bool relevant_voxel(const u32* __restrict__ vox, float min_w, float max_d) {
+  const float d = __uint_as_float(vox[0]), w = __uint_as_float(vox[1]);
+  return w > min_w && fabsf(d) < max_d;
+}
+__global__ void __launch_bounds__(256) k_relevant_count(const u32* __restrict__ voxels, float min_w, float max_d, u32* __restrict__ counts) {
+  __shared__ u32 total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  const u32* blk = voxels + static_cast<size_t>(blockIdx.x) * kVoxelsPerBlock * kWordsPerVoxel;
+  u32 c = 0;
+  for (u32 v = threadIdx.x; v < kVoxelsPerBlock; v += 256) c += relevant_voxel(blk + 3 * v, min_w, max_d) ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&total, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+// one workgroup per block, voxels in linear order: 16 rounds of 256 with an in-order ballot/prefix compaction
+__global__ void __launch_bounds__(256) k_relevant_write(const u32* __restrict__ voxels, const u64* __restrict__ block_keys, const u64* __restrict__ offsets,
+                                                        float min_w, float max_d, float voxel_size, float block_size, float* __restrict__ out) {
+  __shared__ u32 wave_cnt[4];
+  __shared__ u32 base;
+  const u32 pool = blockIdx.x;
+  const u32* blk = voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
+  int bx, by, bz;
+  unpack_key(block_keys[pool], &bx, &by, &bz);
+  const float ox = static_cast<float>(bx) * block_size, oy = static_cast<float>(by) * block_size, oz = static_cast<float>(bz) * block_size;
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  float* dst = out + offsets[pool] * 5ull;
+  for (u32 round = 0; round < kVoxelsPerBlock / 256; ++round) {
+    const u32 v = round * 256 + threadIdx.x;
+    const bool keep = relevant_voxel(blk + 3 * v, min_w, max_d);
+    const u64 m = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = static_cast<u32>(__popcll(m));
+    __syncthreads();
+    u32 pos = base + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
+    for (u32 w = 0; w < wave; ++w) pos += wave_cnt[w];
+    if (keep) {
+      const int lx = static_cast<int>(v & 15u), ly = static_cast<int>((v >> 4) & 15u), lz = static_cast<int>(v >> 8);
+      float* p = dst + static_cast<size_t>(pos) * 5;
+      p[0] = ox + center_coord(lx, voxel_size);
+      p[1] = oy + center_coord(ly, voxel_size);
+      p[2] = oz + center_coord(lz, voxel_size);
+      p[3] = __uint_as_float(blk[3 * v]);
+      p[4] = __uint_as_float(blk[3 * v + 1]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+// builds the point list on the device; *d_out (n*5 floats) is hipMalloc'ed for the caller
+static int relevant_points_device(cox_layer* L, float min_w, float max_d, float** d_out, u64* n_out) {
+  *d_out = nullptr;
+  *n_out = 0;
+  u32 nb, err;
+  int st = layer_read_counters(L, &nb, &err);
+  if (st != COX_OK) return st;
+  if (nb == 0) return COX_OK;
+  u32* d_counts = nullptr;
+  u64* d_off = nullptr;
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_counts), sizeof(u32) * nb));
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_off), sizeof(u64) * nb));
+  hipLaunchKernelGGL(k_relevant_count, dim3(nb), dim3(256), 0, nullptr, L->voxels, min_w, max_d, d_counts);
+  std::vector<u32> counts(nb);
+  std::vector<u64> keys(nb), off(nb);
+  COX_HIP(hipMemcpy(counts.data(), d_counts, sizeof(u32) * nb, hipMemcpyDeviceToHost));
+  COX_HIP(hipMemcpy(keys.data(), L->block_keys, sizeof(u64) * nb, hipMemcpyDeviceToHost));
+  std::vector<u32> order(nb);
+  for (u32 i = 0; i < nb; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return keys[a] < keys[b]; });  // packed key orders (z, y, x)
+  u64 run = 0;
+  for (u32 i = 0; i < nb; ++i) {
+    off[order[i]] = run;
+    run += counts[order[i]];
+  }
+  if (run) {
+    COX_HIP(hipMemcpy(d_off, off.data(), sizeof(u64) * nb, hipMemcpyHostToDevice));
+    float* d_pts = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_pts), sizeof(float) * 5 * run);
+    if (e != hipSuccess) {
+      (void)hipFree(d_counts);
+      (void)hipFree(d_off);
+      return COX_ERR_OUT_OF_MEMORY;
+    }
+    hipLaunchKernelGGL(k_relevant_write, dim3(nb), dim3(256), 0, nullptr, L->voxels, L->block_keys, d_off, min_w, max_d, L->voxel_size, L->block_size, d_pts);
+    COX_HIP(hipDeviceSynchronize());
+    *d_out = d_pts;
+  }
+  *n_out = run;
+  (void)hipFree(d_counts);
+  (void)hipFree(d_off);
+  return COX_OK;
+}
+
+extern "C" int cox_layer_registration_points(cox_layer_t* L, float min_voxel_weight, float max_voxel_distance, float* out, uint64_t cap, uint64_t* n) {
+  COX_ENTRY();
+  if (!L || !n) return COX_ERR_INVALID_ARG;
+  float* d = nullptr;
+  u64 cnt = 0;
+  int st = relevant_points_device(L, min_voxel_weight, max_voxel_distance, &d, &cnt);
+  if (st != COX_OK) return st;
+  *n = cnt;
+  if (out && cnt) {
+    if (cap < cnt) {
+      (void)hipFree(d);
+      return COX_ERR_BUFFER_TOO_SMALL;
+    }
+    COX_HIP(hipMemcpy(out, d, sizeof(float) * 5 * cnt, hipMemcpyDeviceToHost));
+  }
+  if (d) (void)hipFree(d);
+  return COX_OK;
+}
+
+extern "C" int cox_regpoints_from_layer(cox_layer_t* L, float min_voxel_weight, float max_voxel_distance, cox_regpoints_t** out) {
+  COX_ENTRY();
+  if (!L || !out) return COX_ERR_INVALID_ARG;
+  float* d = nullptr;
+  u64 cnt = 0;
+  int st = relevant_points_device(L, min_voxel_weight, max_voxel_distance, &d, &cnt);
+  if (st != COX_OK) return st;
+  cox_regpoints* R = new (std::nothrow) cox_regpoints();
+  if (!R) {
+    if (d) (void)hipFree(d);
+    return COX_ERR_OUT_OF_MEMORY;
+  }
+  R->device = L->device;
+  R->pts = d;
+  R->n = cnt;
+  *out = R;
+  return COX_OK;
+}

@@ -278,11 +278,6 @@ __global__ void __launch_bounds__(256) k_reg_reduce_partials(const double* __res
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------
-struct cox_regpoints {
-  int device = 0;
-  float* pts = nullptr;
-  u64 n = 0;
-};
 struct cox_reg {
   const cox_regpoints* ref = nullptr;
   const cox_layer* reading = nullptr;
@@ -356,6 +351,11 @@ int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, c
     }
   }
   *out = R;
+  return COX_OK;
+}
+int cox_regpoints_size(const cox_regpoints_t* R, uint64_t* n) {
+  if (!R || !n) return COX_ERR_INVALID_ARG;
+  *n = R->n;
   return COX_OK;
 }
 void cox_regpoints_destroy(cox_regpoints_t* R) {

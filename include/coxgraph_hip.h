@@ -159,6 +159,15 @@ typedef struct cox_reg_config {
  * called at utils/msg_converter.h:113): n * {x, y, z, distance, weight} floats. */
 int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, cox_regpoints_t** out);
 void cox_regpoints_destroy(cox_regpoints_t* pts);
+/* VoxgraphSubmap::finishSubmap() -> findRelevantVoxelIndices, as triggered for every received submap at
+ * utils/msg_converter.h:113: the "voxels" (implicit_to_implicit) registration point set = every voxel with
+ * weight > min_voxel_weight and |distance| < max_voxel_distance, position = voxel centre, in (z,y,x) block order and
+ * linear voxel order.  out may be NULL to query n; cox_regpoints_from_layer keeps the set on the GPU. */
+int cox_layer_registration_points(cox_layer_t* layer, float min_voxel_weight, float max_voxel_distance, float* out_xyz_dist_weight, uint64_t cap,
+                                  uint64_t* n);
+int cox_regpoints_from_layer(cox_layer_t* layer, float min_voxel_weight, float max_voxel_distance, cox_regpoints_t** out);
+/* number of points in a set */
+int cox_regpoints_size(const cox_regpoints_t* pts, uint64_t* n);
 /* RegistrationConstraint::Config{first_submap_ptr, second_submap_ptr, registration{...}} as set up
  * by PoseGraphInterface::addForceRegistrationConstraint (src/server/pose_graph_interface.cpp:88-105):
  * reference = first submap's registration points, reading = second submap's TSDF layer. */

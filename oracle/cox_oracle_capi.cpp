@@ -222,6 +222,44 @@ int coxo_regpoints_create(int /*device*/, const float* p, uint64_t n, coxo_regpo
   return COX_OK;
 }
 void coxo_regpoints_destroy(coxo_regpoints* p) { delete p; }
+int coxo_regpoints_size(const coxo_regpoints* p, uint64_t* n) {
+  *n = p->pts.size();
+  return COX_OK;
+}
+// VoxgraphSubmap::finishSubmap -> findRelevantVoxelIndices (called at coxgraph utils/msg_converter.h:113):
+// voxels with weight > min and |distance| < max, position = Block::computeCoordinatesFromLinearIndex,
+// blocks in (z,y,x) order, voxels in linear order.
+static void relevantPoints(const Layer& L, float min_w, float max_d, std::vector<RegPoint>* out) {
+  std::map<std::tuple<int, int, int>, const Block*> sorted;
+  for (auto& kv : L.blocks) sorted[std::make_tuple(kv.first.z, kv.first.y, kv.first.x)] = kv.second.get();
+  for (auto& kv : sorted) {
+    const Block* b = kv.second;
+    for (int lin = 0; lin < L.vps * L.vps * L.vps; ++lin) {
+      const TsdfVoxel& v = b->voxels[lin];
+      if (v.weight > min_w && std::abs(v.distance) < max_d) {
+        const int lx = lin % L.vps, ly = (lin / L.vps) % L.vps, lz = lin / (L.vps * L.vps);
+        out->push_back(RegPoint{b->origin.x + centerCoord(lx, L.voxel_size), b->origin.y + centerCoord(ly, L.voxel_size),
+                                b->origin.z + centerCoord(lz, L.voxel_size), v.distance, v.weight});
+      }
+    }
+  }
+}
+int coxo_layer_registration_points(coxo_layer* l, float min_w, float max_d, float* out, uint64_t cap, uint64_t* n) {
+  std::vector<RegPoint> pts;
+  relevantPoints(l->layer, min_w, max_d, &pts);
+  *n = pts.size();
+  if (out && !pts.empty()) {
+    if (cap < pts.size()) return COX_ERR_BUFFER_TOO_SMALL;
+    std::memcpy(out, pts.data(), pts.size() * sizeof(RegPoint));
+  }
+  return COX_OK;
+}
+int coxo_regpoints_from_layer(coxo_layer* l, float min_w, float max_d, coxo_regpoints** out) {
+  auto* h = new coxo_regpoints();
+  relevantPoints(l->layer, min_w, max_d, &h->pts);
+  *out = h;
+  return COX_OK;
+}
 int coxo_reg_create(const coxo_regpoints* ref, const coxo_layer* reading, const cox_reg_config* cfg, coxo_reg** out) {
   auto* h = new coxo_reg();
   h->ref = ref;

@@ -124,3 +124,19 @@ def test_edge_cases(hip, oracle, submaps):
     assert np.array_equal(rh, ro) or np.max(np.abs(rh - ro)) < 1e-12
     assert not jfh.any()
     assert gh.normal_eq(np.zeros(4), np.zeros(4))[3] == 0
+
+
+def test_registration_points_extracted_on_the_gpu(hip, oracle, submaps):
+    pts, lb, lh = submaps
+    a = lh.registration_points(1.0, 0.3)
+    b = lb.registration_points(1.0, 0.3)
+    assert a.shape == b.shape and a.shape[0] > 1000 and np.array_equal(a, b)
+    # and straight into a device-resident point set used by the cost
+    rp = RegPoints.from_layer(hip, lh, 1.0, 0.3)
+    assert rp.n == len(b)
+    gh = Registration(hip, rp, lh)
+    go = Registration(oracle, RegPoints(oracle, b), lb)
+    pose = np.array([0.02, -0.01, 0.01, 0.005])
+    rh, _, _ = gh.evaluate(np.zeros(4), pose)
+    ro, _, _ = go.evaluate(np.zeros(4), pose)
+    assert np.max(np.abs(rh - ro)) <= 1e-4

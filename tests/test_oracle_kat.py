@@ -302,3 +302,20 @@ def test_wire_format_words(oracle):
     assert d[0, 7] == 0.5 and w[0, 7] == 4.0 and tuple(rgba[0, 7]) == (2, 3, 4, 5)
     layer.upload(np.zeros((0, 3), np.int32), np.zeros((0, 4096, 3), np.uint32), action=2)
     assert layer.stats()[0] == 0
+
+
+def test_registration_points_of_a_layer(oracle):
+    """findRelevantVoxelIndices: weight > min and |d| < max, voxel-centre positions, (z,y,x) block / linear voxel order."""
+    layer = _plane_layer(oracle, voxel=0.1, a=-1.0, bx=1.0, by=0.0, bz=0.0, blocks=((0, 0, 0), (1, 0, 0), (0, 0, 1)))
+    pts = layer.registration_points(min_voxel_weight=1.0, max_voxel_distance=0.3)
+    # d = x - 1 on voxel centres x = 0.05 + 0.1 k: |d| < 0.3 <=> k in 7..12, all inside blocks with x index 0 (0..1.6 m);
+    # 256 (y,z) columns per k in block (0,0,0) and again in block (0,0,1); block (1,0,0) contributes nothing
+    assert pts.shape == (6 * 256 * 2, 5)
+    assert np.allclose(pts[:, 3], pts[:, 0] - 1.0, atol=1e-6) and np.all(pts[:, 4] == 2.0)
+    assert np.all(np.abs(pts[:, 3]) < 0.3)
+    # order: block (0,0,0), then (1,0,0), then (0,0,1); inside a block x fastest
+    assert np.allclose(pts[0, :3], [0.75, 0.05, 0.05]) and np.allclose(pts[1, :3], [0.85, 0.05, 0.05])
+    assert np.all(pts[:6 * 256, 2] < 1.6) and np.all(pts[6 * 256:, 2] > 1.6)
+    assert layer.registration_points(min_voxel_weight=2.0).shape[0] == 0  # strict >
+    rp = RegPoints.from_layer(oracle, layer, 1.0, 0.3)
+    assert rp.n == len(pts)
