@@ -140,3 +140,34 @@ def test_registration_points_extracted_on_the_gpu(hip, oracle, submaps):
     rh, _, _ = gh.evaluate(np.zeros(4), pose)
     ro, _, _ = go.evaluate(np.zeros(4), pose)
     assert np.max(np.abs(rh - ro)) <= 1e-4
+
+
+def test_two_stage_optimize_recovers_a_perturbed_submap_pose(hip, oracle):
+    """The server flow of coxgraph_server.cpp:396-476 on the GPU: two overlapping submaps of one client are fused on the GPU,
+    the second one is handed over (wire format) with a perturbed pose, a loop closure + forced registration constraint are
+    added and PoseGraphInterface::optimize runs its two stages.  Same flow driven by the oracle gives the same poses."""
+    from coxgraph_amd.posegraph import PoseGraphInterface
+    delta = np.array([0.05, -0.03, 0.02, np.radians(1.0)])  # SURVEY.md section 8d perturbation
+    poses = {}
+    for name, eng in (("hip", hip), ("oracle", oracle)):
+        kw = dict(capacity_blocks=4096) if eng is hip else {}
+        la, _, _ = run_frames(eng, method="merged", voxel=0.10, frames=range(0, 60, 5), subsample=6, **kw)
+        lb, _, _ = run_frames(eng, method="merged", voxel=0.10, frames=range(30, 90, 5), subsample=6, **kw)
+        ref_pts = RegPoints.from_layer(eng, la, 1.0, 0.3)
+        assert ref_pts.n > 3000
+        reg = Registration(eng, ref_pts, lb)
+        g = PoseGraphInterface()
+        g.addSubmap(0, [0, 0, 0, 0])
+        g.addSubmap(1, delta)  # both submaps were built in the same world frame: the true relative pose is identity
+        # a sloppy loop closure (place recognition) that is 2 cm / 0.5 deg off, then the registration constraint refines it
+        g.addLoopClosureMeasurement(0, 1, [0.02, 0.0, -0.01, np.radians(0.5)])
+        g.addForceRegistrationConstraint(0, 1, reg)
+        first, second = g.optimize(enable_registration=True)
+        poses[name] = g.getPoseMap()[1]
+        cost0 = reg.normal_eq(np.zeros(4), delta)[2]
+        cost1 = reg.normal_eq(np.zeros(4), poses[name])[2]
+        cost_true = reg.normal_eq(np.zeros(4), np.zeros(4))[2]  # not 0: the two submaps saw the scene from different poses
+        print(name, "pose", poses[name], "registration cost", cost0, "->", cost1, "(at the true pose:", cost_true, ")", second)
+        assert cost1 < 0.6 * cost0 and cost1 < 1.1 * cost_true
+        assert np.linalg.norm(poses[name][:3]) < 0.03 and abs(poses[name][3]) < np.radians(0.6)
+    assert np.allclose(poses["hip"], poses["oracle"], atol=1e-6)
