@@ -32,11 +32,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=300)  # the 300-frame 30 Hz stream of SURVEY.md section 8d
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--method", default="merged", choices=["merged", "simple"])
     ap.add_argument("--voxel", type=float, default=0.05)
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the CPU baseline sample (0 = skip); ~10 s of CPU work at the default")
     ap.add_argument("--reg-iters", type=int, default=50)
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--serial", action="store_true", help="sync after every frame (profiling aid: kernel times without cross-frame overlap)")
@@ -59,7 +59,7 @@ def cpu_baseline(frames, voxel, n_frames, threads):
         layer = Layer(eng, voxel)
         integ = Integrator(eng, layer, cfg, method)
         eng.fn("integrator_set_count_touched")(integ.h, C.c_int(0))
-        nf = n_frames if method == "fast" else max(2, n_frames // 4)
+        nf = n_frames if method == "fast" else max(2, n_frames // 4)  # the single-threaded merged run is context, keep it short
         t0 = time.perf_counter()
         for (T, pts, rgba) in frames[:nf]:
             integ.integrate_points(T, pts, rgba)
@@ -177,22 +177,16 @@ def main():
     # ---- registrations/s: one fused residual+Jacobian+normal-equation evaluation of one constraint ------
     reg = None
     if rank == 0 and args.reg_iters > 0:
-        idx, vox = layer.download()
-        d, w, _ = words_to_fields(vox)
+        from coxgraph_amd.posegraph import PoseGraphInterface
         trunc = cfg.default_truncation_distance
-        lin = np.arange(4096)
-        loc = np.stack([lin % 16, (lin // 16) % 16, lin // 256], axis=1)
-        pts = []
-        for b in range(len(idx)):
-            m = (w[b] > 1.0) & (np.abs(d[b]) < trunc)
-            c = ((idx[b][None, :] * 16 + loc[m]).astype(np.float32) + 0.5) * np.float32(args.voxel)
-            pts.append(np.concatenate([c, d[b][m, None], w[b][m, None]], axis=1))
-        pts = np.concatenate(pts, axis=0).astype(np.float32)
+        # finishSubmap()'s relevant-voxel point set, extracted and kept on the GPU; reading layer = the fused submap itself,
+        # displaced by the SURVEY.md section 8d perturbation
+        ref = RegPoints.from_layer(eng, layer, 1.0, trunc)
+        ww = layer.registration_points(1.0, trunc)[:, 4].astype(np.float64)
         rng = np.random.default_rng(7)
-        ww = pts[:, 4].astype(np.float64)
-        n_res = int(0.3 * len(pts))  # sampling_ratio 0.3, coxgraph/config/server.yaml:30
-        sidx = rng.choice(len(pts), size=n_res, replace=True, p=ww / ww.sum()).astype(np.uint32)
-        g = Registration(eng, RegPoints(eng, pts, device=local_rank), layer)
+        n_res = int(0.3 * ref.n)  # sampling_ratio 0.3, coxgraph/config/server.yaml:30
+        sidx = rng.choice(ref.n, size=n_res, replace=True, p=ww / ww.sum()).astype(np.uint32)
+        g = Registration(eng, ref, layer)
         pr, pd = np.zeros(4), np.array([0.05, -0.03, 0.02, np.radians(1.0)])
         g.normal_eq(pr, pd, sidx)
         g.kernel_time(reset=True)
@@ -201,8 +195,19 @@ def main():
             g.normal_eq(pr, pd, sidx)
         dtr = time.perf_counter() - t1
         kms, kl = g.kernel_time()
-        reg = {"registrations_per_s": args.reg_iters / dtr, "residuals_per_registration": n_res, "registration_points": int(len(pts)),
-               "kernel_ms": kms / max(kl, 1), "kernel_GBps_algorithmic": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9}
+        # full two-stage solve of a 2-node graph (loop closure + forced registration constraint), pose_graph_interface.cpp:32-49
+        pg = PoseGraphInterface()
+        pg.addSubmap(0, [0, 0, 0, 0])
+        pg.addSubmap(1, pd)
+        pg.addLoopClosureMeasurement(0, 1, [0.02, 0.0, -0.01, np.radians(0.5)])
+        pg.addForceRegistrationConstraint(0, 1, g, sidx)
+        t2 = time.perf_counter()
+        _, second = pg.optimize(enable_registration=True)
+        solve_ms = (time.perf_counter() - t2) * 1e3
+        reg = {"registrations_per_s": args.reg_iters / dtr, "residuals_per_registration": n_res, "registration_points": int(ref.n),
+               "kernel_ms": kms / max(kl, 1), "kernel_GBps_algorithmic": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9,
+               "two_stage_solve_ms": solve_ms, "solve_evaluations": second["evaluations"],
+               "solved_pose_error": [float(x) for x in pg.getPoseMap()[1]]}
 
     # ---- CPU baseline on rank 0, N = 1 only ---------------------------------------------------------------
     cpu = None
