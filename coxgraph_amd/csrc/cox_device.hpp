@@ -102,6 +102,15 @@ __device__ __forceinline__ u32 hash_key(u64 k) {
   return static_cast<u32>(k);
 }
 
+// LDS written and then read by the SAME wave needs no hardware barrier (the LDS pipeline is in order per wave), only a
+// compiler fence.  (Do not use `volatile` pointers for this: they decay to generic pointers and compile to flat_load /
+// flat_store sc0 sc1 instead of ds_read / ds_write.)
+__device__ __forceinline__ void wave_lds_handover() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_wave_barrier();
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
 __device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // ---- open-addressing hash set/map on packed keys -------------------------------------------

@@ -265,13 +265,7 @@ __global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __rest
 // LDS read per step and no branches.  The chain length is the bundle size, so the two chains of a big bundle run
 // side by side on different SIMDs instead of back to back.  Skipped points (w < eps, or anything after the first
 // point of a clearing bundle) are the identity step: (M, A, D) = (1, 0, 1).
-typedef float MergeOp __attribute__((ext_vector_type(4)));  // (M, A, D, unused)
-// the table is written and read by the same wave: keep the compiler from moving LDS accesses across the hand-over
-__device__ __forceinline__ void wave_lds_handover() {
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  __builtin_amdgcn_wave_barrier();
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
+typedef float MergeOp __attribute__((ext_vector_type(4)));  // (M, A, D, 1/D)
 __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ bstart, RayArrays R, Counters* cnt) {
   const FrameParams P = *Pp;
   const u32 np2 = P.np2;
@@ -571,7 +565,7 @@ constexpr u32 kRayFallback = 4u;  // ray flag
 
 __device__ __forceinline__ u32 pack_path(u32 jx, u32 jy, u32 jz) { return jx | (jy << 10) | (jz << 20); }
 // entries of the sorted array a[0, n) that precede t: a[i] < t, or a[i] <= t when inclusive
-__device__ __forceinline__ u32 count_before(const volatile float* a, u32 n, float t, bool inclusive) {
+__device__ __forceinline__ u32 count_before(const float* a, u32 n, float t, bool inclusive) {
   u32 lo = 0, hi = n;
   while (lo < hi) {
     const u32 mid = (lo + hi) >> 1;
@@ -603,7 +597,7 @@ __device__ __forceinline__ int dda_step_axis(Dda& d) {
 }
 // Fills path[0, ns) (LDS, this wave's) with the packed per-axis crossing counts of every step.  Returns false
 // when the ray needs the sequential fallback (nothing usable was written).
-__device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, volatile float* tl /*[3][kAxisCap]*/, volatile u32* path, u32 lane) {
+__device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /*[3][kAxisCap]*/, u32* path, u32 lane) {
   if (d0.sgn[0] == 0 || d0.sgn[1] == 0 || d0.sgn[2] == 0) return false;
   const u32 g0 = d0.n_axis[0] + 2, g1 = d0.n_axis[1] + 2, g2 = d0.n_axis[2] + 2;
   if (g0 > kAxisCap || g1 > kAxisCap || g2 > kAxisCap || ns > 3 * kAxisCap) return false;
@@ -612,13 +606,13 @@ __device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, volatile fl
     float T = (lane == 0) ? d0.t_next[0] : (lane == 1) ? d0.t_next[1] : d0.t_next[2];
     const float st = (lane == 0) ? d0.t_step[0] : (lane == 1) ? d0.t_step[1] : d0.t_step[2];
     const u32 g = (lane == 0) ? g0 : (lane == 1) ? g1 : g2;
-    volatile float* row = tl + lane * kAxisCap;
+    float* row = tl + lane * kAxisCap;
     for (u32 j = 0; j < g; ++j) {
       row[j] = T;
       T += st;
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_handover();
   const u32 E = g0 + g1 + g2;
   bool bad = false;
   for (u32 eb = 0; eb < E; eb += 64) {
@@ -641,7 +635,7 @@ __device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, volatile fl
     }
   }
   if (lane == 0) path[0] = 0;
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_handover();
   return __ballot(bad) == 0ull;
 }
 
@@ -679,8 +673,8 @@ __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restric
   const bool overflow = uniform_u32(cnt->n_records) > rec_cap;
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
-  volatile float* tl = lds_t[wave];
-  volatile u32* path = lds_path[wave];
+  float* tl = lds_t[wave];
+  u32* path = lds_path[wave];
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
   for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_slots; r += waves_total) {
     const u32 ns = uniform_u32(R.nsteps[r]);
@@ -715,6 +709,7 @@ __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restric
         if (act && !skip && bkey != prev) touch_block(P, L, bkey, touched_slots, cnt, layer_err);
         carry = __shfl(bkey, 63, 64);
       }
+      wave_lds_handover();  // the next ray of this wave reuses the LDS scratch
     } else if (lane == 0) {
       // sequential fallback
       u64 last_bkey = kEmptyKey;

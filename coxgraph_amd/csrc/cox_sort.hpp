@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
     }
     __syncthreads();
     // pass 2: stable placement.  Order = (tile, wave, round, lane) = input order.
-    volatile u32* my_base = base[wave];
+    u32* my_base = base[wave];
     for (int r = 0; r < kRsRounds; ++r) {
       const u32 i = wstart + r * 64 + lane;
       const bool valid = i < n;
@@ -278,9 +278,9 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
         keys_out[pos] = key;
         vals_out[pos] = val;
       }
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_handover();
       if (valid && lower == 0ull) my_base[digit] += static_cast<u32>(__popcll(peers));  // group leader
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_handover();
     }
     __syncthreads();
   }
