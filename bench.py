@@ -166,8 +166,17 @@ def main():
             per_launch_bytes = alg_bytes / launches
             avg_ms = ms / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (profiles/, same command with --serial): rocprofv3 cannot
+            # run inside this process, so the figure is read back from the summary it produced
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                names = kernels[stage].split("+")
+                traffic = sum(pm[k]["fetch_bytes"] + pm[k]["write_bytes"] for k in names)
+            except Exception:
+                traffic = None
             roofline = {"bound": "hbm", "kernel": kernels[stage], "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms,
                         "algorithmic_bytes_per_launch": per_launch_bytes,
                         "note": "one launch = one frame; the path is bound by dependent in-order update chains, not by HBM, at 5 cm (DESIGN.md section 6)",
                         "stage_avg_ms": {kernels[k]: (v[0] / v[1] if v[1] else None) for k, v in st.items()},
