@@ -125,6 +125,14 @@ constexpr int kRsRounds = 8;
 constexpr int kRsWaveTile = 64 * kRsRounds;      // 512 elements per wave
 constexpr int kRsTile = kRsWaveTile * kRsWaves;  // 2048 elements per tile (smaller: the 2048-bin histograms dominate; larger: too few workgroups)
 constexpr int kRsMaxPasses = 4;
+constexpr u32 kRsMaxTiles = 4096;  // beyond this many tiles the tile doubles: the 2^RB x tiles histogram matrix must stay small next to the data
+
+// log2(tile / kRsTile): the smallest k with n <= kRsMaxTiles * (kRsTile << k).  Computed identically by all three kernels.
+__device__ __forceinline__ u32 rs_tile_shift(u32 n) {
+  u32 k = 0;
+  while ((static_cast<u64>(kRsMaxTiles) * kRsTile << k) < n) ++k;
+  return k;
+}
 
 // device-side description of one sort
 struct SortInfo {
@@ -142,12 +150,13 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ 
   if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
   const u32* keys = (pass & 1) ? k1 : k0;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
-  const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
+  const u32 tile_elems = static_cast<u32>(kRsTile) << rs_tile_shift(n);
+  const u32 n_tiles = (n + tile_elems - 1) / tile_elems;
   for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) h[d] = 0;
     __syncthreads();
-    const u32 start = tile * kRsTile;
-    for (u32 i = start + threadIdx.x; i < start + kRsTile && i < n; i += kRsThreads) atomicAdd(&h[(keys[i] >> shift) & (kDigits - 1)], 1u);
+    const u64 start = static_cast<u64>(tile) * tile_elems;
+    for (u64 i = start + threadIdx.x; i < start + tile_elems && i < n; i += kRsThreads) atomicAdd(&h[(keys[i] >> shift) & (kDigits - 1)], 1u);
     __syncthreads();
     for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) {
       const u32 c = h[d];
@@ -174,7 +183,8 @@ __global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restr
   const int shift = pass * RB;
   if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
-  const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
+  const u32 tile_elems = static_cast<u32>(kRsTile) << rs_tile_shift(n);
+  const u32 n_tiles = (n + tile_elems - 1) / tile_elems;
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const u32 d0 = blockIdx.x * 64u;  // first digit of this group
   // sum of the totals of all digits below the group
@@ -235,17 +245,21 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
   u32* keys_out = (pass & 1) ? k0 : k1;
   u32* vals_out = (pass & 1) ? v0 : v1;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
-  const u32 n_tiles = (n + kRsTile - 1) / kRsTile;
+  const u32 tshift = rs_tile_shift(n);
+  const u32 tile_elems = static_cast<u32>(kRsTile) << tshift;
+  const u32 wave_elems = static_cast<u32>(kRsWaveTile) << tshift;  // contiguous elements per wave
+  const u32 rounds = static_cast<u32>(kRsRounds) << tshift;
+  const u32 n_tiles = (n + tile_elems - 1) / tile_elems;
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
   for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     for (u32 w = 0; w < kRsWaves; ++w)
       for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) base[w][d] = 0;
     __syncthreads();
-    const u32 wstart = tile * kRsTile + wave * kRsWaveTile;
+    const u64 wstart = static_cast<u64>(tile) * tile_elems + static_cast<u64>(wave) * wave_elems;
     // pass 1: per-wave digit counts of this wave's contiguous sub-tile
-    for (int r = 0; r < kRsRounds; ++r) {
-      const u32 i = wstart + r * 64 + lane;
+    for (u32 r = 0; r < rounds; ++r) {
+      const u64 i = wstart + static_cast<u64>(r) * 64 + lane;
       if (i < n) atomicAdd(&base[wave][(keys_in[i] >> shift) & (kDigits - 1)], 1u);
     }
     __syncthreads();
@@ -262,8 +276,8 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
     __syncthreads();
     // pass 2: stable placement.  Order = (tile, wave, round, lane) = input order.
     u32* my_base = base[wave];
-    for (int r = 0; r < kRsRounds; ++r) {
-      const u32 i = wstart + r * 64 + lane;
+    for (u32 r = 0; r < rounds; ++r) {
+      const u64 i = wstart + static_cast<u64>(r) * 64 + lane;
       const bool valid = i < n;
       u32 key = 0, val = 0;
       if (valid) {
