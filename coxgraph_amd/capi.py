@@ -132,6 +132,11 @@ class Layer:
             self.eng.check(f(self.h, _fp(idx), _fp(vox), C.c_uint64(nb), C.byref(n)), "layer_download")
         return idx, vox
 
+    def merge_from(self, other, T_B_A=None):
+        """mergeLayerAintoLayerB(other, [T_B_A,] self)."""
+        T = None if T_B_A is None else np.ascontiguousarray(T_B_A, np.float32)
+        self.eng.check(self.eng.fn("layer_merge")(other.h, _fp(T) if T is not None else None, self.h), "layer_merge")
+
     def registration_points(self, min_voxel_weight=1.0, max_voxel_distance=0.3):
         """finishSubmap()'s relevant voxels: float32 [n,5] = x, y, z, distance, weight."""
         n = C.c_uint64()

@@ -253,13 +253,14 @@ __global__ void k_upload_insert(u64* ht_keys, u32* ht_vals, u32 ht_mask, u64* bl
   }
 }
 // one workgroup per uploaded block; action 0/2: overwrite, 1: mergeVoxelAIntoVoxelB
-__global__ void __launch_bounds__(256) k_upload_copy(u32* __restrict__ voxels, const u32* __restrict__ src, const u32* __restrict__ pool_of, int action) {
+__global__ void __launch_bounds__(256) k_upload_copy(u32* __restrict__ voxels, const u32* __restrict__ src, const u32* __restrict__ src_index,
+                                                     const u32* __restrict__ pool_of, int action) {
   const u32 b = blockIdx.x;
   const u32 p = pool_of[b];
   if (p == kInvalid) return;
   const u32 pool = p & 0x7FFFFFFFu;
   u32* dst = voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
-  const u32* s = src + static_cast<size_t>(b) * kVoxelsPerBlock * kWordsPerVoxel;
+  const u32* s = src + static_cast<size_t>(src_index ? src_index[b] : b) * kVoxelsPerBlock * kWordsPerVoxel;
   if (action != 1) {
     for (u32 i = threadIdx.x; i < kVoxelsPerBlock * kWordsPerVoxel; i += blockDim.x) dst[i] = s[i];
     return;
@@ -304,7 +305,7 @@ extern "C" int cox_layer_upload(cox_layer_t* L, const int32_t* block_idx_xyz, co
   const u32 n = static_cast<u32>(n_blocks);
   hipLaunchKernelGGL(k_upload_insert, dim3((n + 255) / 256), dim3(256), 0, nullptr, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->block_keys,
                      L->d_nblocks, static_cast<u32>(L->capacity), L->d_err, d_idx, n, d_pool);
-  hipLaunchKernelGGL(k_upload_copy, dim3(n), dim3(256), 0, nullptr, L->voxels, d_src, d_pool, action);
+  hipLaunchKernelGGL(k_upload_copy, dim3(n), dim3(256), 0, nullptr, L->voxels, d_src, static_cast<const u32*>(nullptr), d_pool, action);
   COX_HIP(hipDeviceSynchronize());
   (void)hipFree(d_idx);
   (void)hipFree(d_src);
@@ -456,4 +457,307 @@ extern "C" int cox_regpoints_from_layer(cox_layer_t* L, float min_voxel_weight, 
   R->n = cnt;
   *out = R;
   return COX_OK;
+}
+
+// =================================================================================================
+// mergeLayerAintoLayerB(A, [T_B_A,] B)   (voxblox merge_integration.h)
+// =================================================================================================
+// coxgraph call sites: the client's combined map (coxgraph/src/client/map_server.cpp:59-73) and the server's
+// mergeToCliMap (coxgraph/src/server/submap_collection.cpp:24-37).  With a transform, layer A is first resampled onto
+// B's grid (transformLayer: candidate output blocks from the transformed block centres, every output voxel centre taken
+// back into A and interpolated trilinearly, nearest voxel if that fails, blocks without data dropped), then merged
+// voxel by voxel (mergeVoxelAIntoVoxelB).
+struct LayerConstView {
+  const u32* voxels;
+  const u64* ht_keys;
+  const u32* ht_vals;
+  u32 ht_mask;
+  float voxel_size, voxel_size_inv, block_size, block_size_inv;
+};
+struct RigidParams {
+  float qw, qx, qy, qz, tx, ty, tz;
+};
+__device__ __forceinline__ F3 rigid_apply(const RigidParams& T, F3 v) {
+  const F3 qv{T.qx, T.qy, T.qz};
+  F3 uv = cross3(qv, v);
+  uv = uv + uv;
+  const F3 c = cross3(qv, uv);
+  return F3{((v.x + T.qw * uv.x) + c.x) + T.tx, ((v.y + T.qw * uv.y) + c.y) + T.ty, ((v.z + T.qw * uv.z) + c.z) + T.tz};
+}
+__constant__ float c_merge_interp_table[8][8] = {{1, 0, 0, 0, 0, 0, 0, 0},   {-1, 0, 0, 0, 1, 0, 0, 0},   {-1, 0, 1, 0, 0, 0, 0, 0},
+                                                 {-1, 1, 0, 0, 0, 0, 0, 0},  {1, 0, -1, 0, -1, 0, 1, 0},  {1, -1, -1, 1, 0, 0, 0, 0},
+                                                 {1, -1, 0, 0, -1, 1, 0, 0}, {-1, 1, 1, -1, 1, -1, -1, 1}};
+__device__ __forceinline__ float interp_member(const float q[8], const float data[8]) {
+  float md[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += c_merge_interp_table[r][c] * data[c];
+    md[r] = s;
+  }
+  float v = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v += q[i] * md[i];
+  return v;
+}
+__device__ __forceinline__ const u32* voxel_words(const LayerConstView& L, u32 pool, int vx, int vy, int vz) {
+  return L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + static_cast<u32>(vx + 16 * (vy + 16 * vz))) * kWordsPerVoxel;
+}
+// Interpolator::getVoxel(pos, &voxel, true) || getVoxel(pos, &voxel, false); returns false when neither is possible
+__device__ __forceinline__ bool resample_voxel(const LayerConstView& L, const float pos[3], u32 out[3]) {
+  float sc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sc[k] = pos[k] * L.block_size_inv;
+  if (!(index_in_range(sc[0]) && index_in_range(sc[1]) && index_in_range(sc[2]))) return false;
+  int b0[3], v0[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b0[k] = grid_index(sc[k]);
+  const u32 slot0 = ht_find(L.ht_keys, L.ht_mask, pack_key(b0[0], b0[1], b0[2]));
+  if (slot0 == kInvalid) return false;
+  const u32 pool0 = L.ht_vals[slot0];
+  if (pool0 == kInvalid) return false;
+  int b[3], vi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float origin = static_cast<float>(b0[k]) * L.block_size;
+    int v = grid_index((pos[k] - origin) * L.voxel_size_inv);
+    v = v > 15 ? 15 : (v < 0 ? 0 : v);
+    v0[k] = v;
+    b[k] = b0[k];
+    const float c = origin + center_coord(v, L.voxel_size);
+    if (pos[k] - c < 0.0f) {
+      v--;
+      if (v < 0) {
+        b[k]--;
+        v += 16;
+      }
+    }
+    vi[k] = v;
+  }
+  // ---- trilinear ----
+  bool ok = true;
+  u32 base_pool = pool0;
+  if (b[0] != b0[0] || b[1] != b0[1] || b[2] != b0[2]) {
+    const u32 sl = ht_find(L.ht_keys, L.ht_mask, pack_key(b[0], b[1], b[2]));
+    base_pool = (sl == kInvalid) ? kInvalid : L.ht_vals[sl];
+    ok = base_pool != kInvalid;
+  }
+  float d[8], w[8], ch[4][8];
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (!ok) break;
+      int v[3] = {vi[0] + ((i >> 2) & 1), vi[1] + ((i >> 1) & 1), vi[2] + (i & 1)};
+      int nb[3] = {b[0], b[1], b[2]};
+      bool moved = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (v[k] >= 16) {
+          nb[k]++;
+          v[k] -= 16;
+          moved = true;
+        }
+      u32 pool = base_pool;
+      if (moved) {
+        const u32 sl = ht_find(L.ht_keys, L.ht_mask, pack_key(nb[0], nb[1], nb[2]));
+        pool = (sl == kInvalid) ? kInvalid : L.ht_vals[sl];
+        if (pool == kInvalid) {
+          ok = false;
+          break;
+        }
+      }
+      const u32* vw = voxel_words(L, pool, v[0], v[1], v[2]);
+      const float wi = __uint_as_float(vw[1]);
+      if (!(wi > 0.0f)) {
+        ok = false;
+        break;
+      }
+      d[i] = __uint_as_float(vw[0]);
+      w[i] = wi;
+      const u32 c = vw[2];
+      ch[0][i] = static_cast<float>(static_cast<int>((c >> 24) & 255u));  // r
+      ch[1][i] = static_cast<float>(static_cast<int>((c >> 16) & 255u));  // g
+      ch[2][i] = static_cast<float>(static_cast<int>((c >> 8) & 255u));   // b
+      ch[3][i] = static_cast<float>(static_cast<int>(c & 255u));          // a
+    }
+  }
+  if (ok) {
+    float off[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float c0 = static_cast<float>(b[k]) * L.block_size + center_coord(vi[k], L.voxel_size);
+      off[k] = (pos[k] - c0) * L.voxel_size_inv;
+    }
+    const float dx = off[0], dy = off[1], dz = off[2];
+    const float q[8] = {1.0f, dx, dy, dz, dx * dy, dy * dz, dz * dx, dx * dy * dz};
+    out[0] = __float_as_uint(interp_member(q, d));
+    out[1] = __float_as_uint(interp_member(q, w));
+    const u32 r = static_cast<u32>(static_cast<int>(interp_member(q, ch[0]))) & 255u, g = static_cast<u32>(static_cast<int>(interp_member(q, ch[1]))) & 255u;
+    const u32 bl = static_cast<u32>(static_cast<int>(interp_member(q, ch[2]))) & 255u, a = static_cast<u32>(static_cast<int>(interp_member(q, ch[3]))) & 255u;
+    out[2] = a | (bl << 8) | (g << 16) | (r << 24);
+    return true;
+  }
+  // ---- nearest voxel of the block that contains pos ----
+  const u32* vw = voxel_words(L, pool0, v0[0], v0[1], v0[2]);
+  out[0] = vw[0];
+  out[1] = vw[1];
+  out[2] = vw[2];
+  return true;
+}
+// one workgroup per candidate output block
+__global__ void __launch_bounds__(256) k_resample_blocks(LayerConstView A, RigidParams T_in_out, const int32_t* __restrict__ cand_idx, float voxel_size_out,
+                                                         float block_size_out, u32* __restrict__ tmp, u32* __restrict__ has_data) {
+  const u32 c = blockIdx.x;
+  const float ox = static_cast<float>(cand_idx[3 * c]) * block_size_out, oy = static_cast<float>(cand_idx[3 * c + 1]) * block_size_out,
+              oz = static_cast<float>(cand_idx[3 * c + 2]) * block_size_out;
+  u32* dst = tmp + static_cast<size_t>(c) * kVoxelsPerBlock * kWordsPerVoxel;
+  bool any = false;
+  for (u32 v = threadIdx.x; v < kVoxelsPerBlock; v += 256) {
+    const int lx = static_cast<int>(v & 15u), ly = static_cast<int>((v >> 4) & 15u), lz = static_cast<int>(v >> 8);
+    const F3 centre{ox + center_coord(lx, voxel_size_out), oy + center_coord(ly, voxel_size_out), oz + center_coord(lz, voxel_size_out)};
+    const F3 p = rigid_apply(T_in_out, centre);
+    const float pos[3] = {p.x, p.y, p.z};
+    u32 w[3];
+    if (resample_voxel(A, pos, w)) {
+      dst[3 * v] = w[0];
+      dst[3 * v + 1] = w[1];
+      dst[3 * v + 2] = w[2];
+      any = true;
+    }
+  }
+  if (__ballot(any) && (threadIdx.x & 63u) == 0) atomicOr(&has_data[c], 1u);
+}
+
+// merge n device-resident blocks (indices d_idx, words src[src_index[i]]) into L, voxel by voxel
+static int merge_device_blocks(cox_layer* L, const int32_t* d_idx, const u32* d_src, const u32* d_src_index, u32 n) {
+  if (n == 0) return COX_OK;
+  u32* d_pool = nullptr;
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pool), sizeof(u32) * n));
+  hipLaunchKernelGGL(k_upload_insert, dim3((n + 255) / 256), dim3(256), 0, nullptr, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->block_keys, L->d_nblocks,
+                     static_cast<u32>(L->capacity), L->d_err, d_idx, n, d_pool);
+  hipLaunchKernelGGL(k_upload_copy, dim3(n), dim3(256), 0, nullptr, L->voxels, d_src, d_src_index, d_pool, 1);
+  COX_HIP(hipDeviceSynchronize());
+  (void)hipFree(d_pool);
+  return COX_OK;
+}
+
+static void host_rotate(const float q[4], const float v[3], float out[3]) {  // Eigen _transformVector, same op order as the kernels
+  const float qv[3] = {q[1], q[2], q[3]};
+  float uv[3] = {qv[1] * v[2] - qv[2] * v[1], qv[2] * v[0] - qv[0] * v[2], qv[0] * v[1] - qv[1] * v[0]};
+  for (int k = 0; k < 3; ++k) uv[k] = uv[k] + uv[k];
+  const float c[3] = {qv[1] * uv[2] - qv[2] * uv[1], qv[2] * uv[0] - qv[0] * uv[2], qv[0] * uv[1] - qv[1] * uv[0]};
+  for (int k = 0; k < 3; ++k) out[k] = (v[k] + q[0] * uv[k]) + c[k];
+}
+static float host_center_coord(int idx, float size) { return static_cast<float>((static_cast<float>(idx) + 0.5) * size); }
+
+extern "C" int cox_layer_merge(const cox_layer_t* A_, const float T_B_A[7], cox_layer_t* B) {
+  COX_ENTRY();
+  cox_layer* A = const_cast<cox_layer*>(A_);
+  if (!A || !B || A == B || A->device != B->device) return COX_ERR_INVALID_ARG;
+  u32 na, ea;
+  int st = layer_read_counters(A, &na, &ea);
+  if (st != COX_OK) return st;
+  if (na == 0) return COX_OK;
+  std::vector<u64> keys(na);
+  COX_HIP(hipMemcpy(keys.data(), A->block_keys, sizeof(u64) * na, hipMemcpyDeviceToHost));
+  if (!T_B_A) {
+    // same grid: block i of A's pool goes to the block with the same index in B
+    if (A->voxel_size != B->voxel_size) return COX_ERR_INVALID_ARG;
+    std::vector<int32_t> idx(3 * static_cast<size_t>(na));
+    for (u32 i = 0; i < na; ++i) unpack_key(keys[i], &idx[3 * i], &idx[3 * i + 1], &idx[3 * i + 2]);
+    int32_t* d_idx = nullptr;
+    COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), sizeof(int32_t) * idx.size()));
+    COX_HIP(hipMemcpy(d_idx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice));
+    st = merge_device_blocks(B, d_idx, A->voxels, nullptr, na);
+    (void)hipFree(d_idx);
+  } else {
+    // candidate output blocks (transformLayer): input blocks in (z,y,x) order, a float-stepped box around each transformed centre
+    std::sort(keys.begin(), keys.end());
+    const float q[4] = {T_B_A[0], T_B_A[1], T_B_A[2], T_B_A[3]};
+    const float kDiag = static_cast<float>(1.7320508075688772);
+    const float inv_out = 1.0f / B->block_size;
+    const float offset = static_cast<float>(kDiag * A->block_size * 0.5);
+    std::vector<int32_t> cand;
+    std::vector<u64> seen;  // sorted-unique check through a hash set would do; candidate counts are small (a few thousand)
+    {
+      std::vector<u64> set_keys;
+      for (u32 i = 0; i < na; ++i) {
+        int bx, by, bz;
+        unpack_key(keys[i], &bx, &by, &bz);
+        const float c_in[3] = {host_center_coord(bx, A->block_size), host_center_coord(by, A->block_size), host_center_coord(bz, A->block_size)};
+        float r[3];
+        host_rotate(q, c_in, r);
+        const float c_out[3] = {r[0] + T_B_A[4], r[1] + T_B_A[5], r[2] + T_B_A[6]};
+        for (float x = c_out[0] - offset; x < c_out[0] + offset; x += B->block_size)
+          for (float y = c_out[1] - offset; y < c_out[1] + offset; y += B->block_size)
+            for (float z = c_out[2] - offset; z < c_out[2] + offset; z += B->block_size) {
+              const int ix = static_cast<int>(std::floor(x * inv_out + 1e-6f)), iy = static_cast<int>(std::floor(y * inv_out + 1e-6f)),
+                        iz = static_cast<int>(std::floor(z * inv_out + 1e-6f));
+              if (ix < -kIdxBias + 1 || ix >= kIdxBias - 1 || iy < -kIdxBias + 1 || iy >= kIdxBias - 1 || iz < -kIdxBias + 1 || iz >= kIdxBias - 1)
+                return COX_ERR_INDEX_RANGE;
+              const u64 k = static_cast<u64>(static_cast<u32>(ix + kIdxBias)) | (static_cast<u64>(static_cast<u32>(iy + kIdxBias)) << 21) |
+                            (static_cast<u64>(static_cast<u32>(iz + kIdxBias)) << 42);
+              set_keys.push_back(k);
+            }
+      }
+      std::sort(set_keys.begin(), set_keys.end());
+      set_keys.erase(std::unique(set_keys.begin(), set_keys.end()), set_keys.end());
+      cand.resize(3 * set_keys.size());
+      for (size_t i = 0; i < set_keys.size(); ++i) unpack_key(set_keys[i], &cand[3 * i], &cand[3 * i + 1], &cand[3 * i + 2]);
+    }
+    const u32 nc = static_cast<u32>(cand.size() / 3);
+    if (nc == 0) return COX_OK;
+    // inverse transform (minkindr: conjugate rotation, -R^T t)
+    const float qi[4] = {q[0], -q[1], -q[2], -q[3]};
+    const float tvec[3] = {T_B_A[4], T_B_A[5], T_B_A[6]};
+    float rt[3];
+    host_rotate(qi, tvec, rt);
+    const RigidParams Tinv{qi[0], qi[1], qi[2], qi[3], -rt[0], -rt[1], -rt[2]};
+    const size_t block_words = static_cast<size_t>(kVoxelsPerBlock) * kWordsPerVoxel;
+    int32_t* d_cand = nullptr;
+    u32 *d_tmp = nullptr, *d_has = nullptr;
+    COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cand), sizeof(int32_t) * cand.size()));
+    COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_has), sizeof(u32) * nc));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_tmp), sizeof(u32) * block_words * nc);
+    if (e != hipSuccess) {
+      (void)hipFree(d_cand);
+      (void)hipFree(d_has);
+      return COX_ERR_OUT_OF_MEMORY;
+    }
+    COX_HIP(hipMemcpy(d_cand, cand.data(), sizeof(int32_t) * cand.size(), hipMemcpyHostToDevice));
+    COX_HIP(hipMemset(d_has, 0, sizeof(u32) * nc));
+    COX_HIP(hipMemset(d_tmp, 0, sizeof(u32) * block_words * nc));
+    const LayerConstView AV{A->voxels, A->ht_keys, A->ht_vals, A->ht_cap - 1, A->voxel_size, A->voxel_size_inv, A->block_size, A->block_size_inv};
+    hipLaunchKernelGGL(k_resample_blocks, dim3(nc), dim3(256), 0, nullptr, AV, Tinv, d_cand, B->voxel_size, B->block_size, d_tmp, d_has);
+    std::vector<u32> has(nc);
+    COX_HIP(hipMemcpy(has.data(), d_has, sizeof(u32) * nc, hipMemcpyDeviceToHost));
+    std::vector<int32_t> keep_idx;
+    std::vector<u32> keep_src;
+    for (u32 i = 0; i < nc; ++i)
+      if (has[i]) {
+        keep_idx.insert(keep_idx.end(), {cand[3 * i], cand[3 * i + 1], cand[3 * i + 2]});
+        keep_src.push_back(i);
+      }
+    const u32 nk = static_cast<u32>(keep_src.size());
+    if (nk) {
+      int32_t* d_idx = nullptr;
+      u32* d_srcidx = nullptr;
+      COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), sizeof(int32_t) * keep_idx.size()));
+      COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_srcidx), sizeof(u32) * nk));
+      COX_HIP(hipMemcpy(d_idx, keep_idx.data(), sizeof(int32_t) * keep_idx.size(), hipMemcpyHostToDevice));
+      COX_HIP(hipMemcpy(d_srcidx, keep_src.data(), sizeof(u32) * nk, hipMemcpyHostToDevice));
+      st = merge_device_blocks(B, d_idx, d_tmp, d_srcidx, nk);
+      (void)hipFree(d_idx);
+      (void)hipFree(d_srcidx);
+    }
+    (void)hipFree(d_cand);
+    (void)hipFree(d_has);
+    (void)hipFree(d_tmp);
+  }
+  if (st != COX_OK) return st;
+  u32 nb, err;
+  st = layer_read_counters(B, &nb, &err);
+  if (st != COX_OK) return st;
+  return err_bits_to_status(err);
 }

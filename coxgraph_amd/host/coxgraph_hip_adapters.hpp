@@ -121,6 +121,15 @@ inline bool deserializeMsgToLayer(const LayerMsg& msg, TsdfLayer* layer) {
   return cox_layer_upload(layer->handle(), idx.data(), words.data(), n, msg.action) == COX_OK;
 }
 
+// voxblox::mergeLayerAintoLayerB(layer_A, layer_B) and (layer_A, T_B_A, layer_B)   (src/client/map_server.cpp:67-69,
+// src/server/submap_collection.cpp:31-33)
+inline void mergeLayerAintoLayerB(const TsdfLayer& layer_A, TsdfLayer* layer_B) { check(cox_layer_merge(layer_A.handle(), nullptr, layer_B->handle()), "mergeLayerAintoLayerB"); }
+inline void mergeLayerAintoLayerB(const TsdfLayer& layer_A, const Transformation& T_B_A, TsdfLayer* layer_B) {
+  float T[7];
+  T_B_A.pack(T);
+  check(cox_layer_merge(layer_A.handle(), T, layer_B->handle()), "mergeLayerAintoLayerB");
+}
+
 // voxblox::TsdfIntegratorBase::Config
 struct TsdfIntegratorConfig : cox_tsdf_config {
   TsdfIntegratorConfig() { cox_tsdf_config_default(this); }

@@ -117,6 +117,11 @@ int cox_layer_download(cox_layer_t* layer, int32_t* block_idx_xyz, uint32_t* vox
  * blocks), 1 = merge (mergeVoxelAIntoVoxelB per voxel), 2 = reset (clear first, then update) */
 int cox_layer_upload(cox_layer_t* layer, const int32_t* block_idx_xyz, const uint32_t* voxels_3u32, uint64_t n_blocks, int action);
 
+/* mergeLayerAintoLayerB(layer_A, [T_B_A,] layer_B)  (src/client/map_server.cpp:67-69, src/server/submap_collection.cpp:31-33):
+ * T_B_A = NULL merges on the same grid (mergeVoxelAIntoVoxelB per voxel); otherwise A is first resampled onto B's grid
+ * (transformLayer: trilinear, nearest voxel where that fails, blocks without data dropped).  Both layers on one GPU. */
+int cox_layer_merge(const cox_layer_t* layer_A, const float T_B_A[7], cox_layer_t* layer_B);
+
 /* ---- TsdfIntegratorBase -------------------------------------------------------------------- */
 /* TsdfIntegratorFactory::create(method, config, layer) */
 int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out);

@@ -36,6 +36,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -753,6 +754,166 @@ inline void interpValueAndGrad(const Interp& it, float voxel_size_inv, float* va
   grad[0] = gx * voxel_size_inv;
   grad[1] = gy * voxel_size_inv;
   grad[2] = gz * voxel_size_inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A.8 layer merge / rigid resample (voxblox merge_integration.h), as coxgraph calls it:
+//   mergeLayerAintoLayerB(layer, T, layer)   coxgraph/src/client/map_server.cpp:67-69, src/server/submap_collection.cpp:31-33
+// ---------------------------------------------------------------------------------------------
+inline Transform inverse(const Transform& T) {
+  Transform I;
+  I.qw = T.qw;
+  I.qx = -T.qx;
+  I.qy = -T.qy;
+  I.qz = -T.qz;
+  I.t = {0.0f, 0.0f, 0.0f};
+  const V3 r = rotate(I, T.t);
+  I.t = {-r.x, -r.y, -r.z};
+  return I;
+}
+// Interpolator<TsdfVoxel>::interpVoxel: distance, weight and the four colour channels each through the same
+// q . (table . data) form; colour channels are narrowed to uint8 by truncation
+inline float interpMember(const float q[8], const float data[8]) {
+  float md[8];
+  for (int r = 0; r < 8; ++r) {
+    float s = 0.0f;
+    for (int c = 0; c < 8; ++c) s += kInterpTable[r][c] * data[c];
+    md[r] = s;
+  }
+  float v = 0.0f;
+  for (int i = 0; i < 8; ++i) v += q[i] * md[i];
+  return v;
+}
+// Interpolator::getVoxel(pos, &voxel, interpolate = true) then, if that fails, interpolate = false (nearest)
+inline bool resampleVoxel(const Layer& L, V3 pos, TsdfVoxel* out) {
+  // ---- trilinear ----
+  {
+    BIdx bi = blockIndexFromPoint(pos, L.block_size_inv);
+    const Block* blk = L.getBlockPtr(bi);
+    if (blk) {
+      const V3 rel = pos - blk->origin;
+      GIdx gi = gridIndexFromPoint(rel, L.voxel_size_inv);
+      int vi[3] = {static_cast<int>(gi.x), static_cast<int>(gi.y), static_cast<int>(gi.z)};
+      for (int k = 0; k < 3; ++k) vi[k] = std::max(std::min(vi[k], L.vps - 1), 0);
+      const float c[3] = {blk->origin.x + centerCoord(vi[0], L.voxel_size), blk->origin.y + centerCoord(vi[1], L.voxel_size),
+                          blk->origin.z + centerCoord(vi[2], L.voxel_size)};
+      const float p[3] = {pos.x, pos.y, pos.z};
+      int b[3] = {bi.x, bi.y, bi.z};
+      for (int k = 0; k < 3; ++k)
+        if (p[k] - c[k] < 0.0f) {
+          vi[k]--;
+          if (vi[k] < 0) {
+            b[k]--;
+            vi[k] += L.vps;
+          }
+        }
+      const BIdx base{b[0], b[1], b[2]};
+      const Block* base_blk = L.getBlockPtr(base);
+      bool ok = base_blk != nullptr;
+      float d[8], w[8], ch[4][8], off[3] = {0, 0, 0};
+      static const int offs[8][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 1, 1}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}};
+      for (int i = 0; i < 8 && ok; ++i) {
+        int v[3] = {vi[0] + offs[i][0], vi[1] + offs[i][1], vi[2] + offs[i][2]};
+        BIdx nb = base;
+        int* nbp[3] = {&nb.x, &nb.y, &nb.z};
+        for (int k = 0; k < 3; ++k)
+          if (v[k] >= L.vps) {
+            (*nbp[k])++;
+            v[k] -= L.vps;
+          }
+        const Block* bp = (nb == base) ? base_blk : L.getBlockPtr(nb);
+        if (!bp) {
+          ok = false;
+          break;
+        }
+        if (i == 0) {
+          const float c0[3] = {bp->origin.x + centerCoord(v[0], L.voxel_size), bp->origin.y + centerCoord(v[1], L.voxel_size),
+                               bp->origin.z + centerCoord(v[2], L.voxel_size)};
+          for (int k = 0; k < 3; ++k) off[k] = (p[k] - c0[k]) * L.voxel_size_inv;
+        }
+        const TsdfVoxel& vox = bp->voxels[linearIndex(v[0], v[1], v[2], L.vps)];
+        if (!(vox.weight > 0.0f)) {
+          ok = false;
+          break;
+        }
+        d[i] = vox.distance;
+        w[i] = vox.weight;
+        ch[0][i] = vox.color.r;
+        ch[1][i] = vox.color.g;
+        ch[2][i] = vox.color.b;
+        ch[3][i] = vox.color.a;
+      }
+      if (ok) {
+        const float dx = off[0], dy = off[1], dz = off[2];
+        const float q[8] = {1.0f, dx, dy, dz, dx * dy, dy * dz, dz * dx, dx * dy * dz};
+        out->distance = interpMember(q, d);
+        out->weight = interpMember(q, w);
+        out->color.r = static_cast<uint8_t>(static_cast<int>(interpMember(q, ch[0])));
+        out->color.g = static_cast<uint8_t>(static_cast<int>(interpMember(q, ch[1])));
+        out->color.b = static_cast<uint8_t>(static_cast<int>(interpMember(q, ch[2])));
+        out->color.a = static_cast<uint8_t>(static_cast<int>(interpMember(q, ch[3])));
+        return true;
+      }
+    }
+  }
+  // ---- nearest: Block::getVoxelByCoordinates ----
+  const BIdx bi = blockIndexFromPoint(pos, L.block_size_inv);
+  const Block* blk = L.getBlockPtr(bi);
+  if (!blk) return false;
+  const V3 rel = pos - blk->origin;
+  const GIdx gi = gridIndexFromPoint(rel, L.voxel_size_inv);
+  int vi[3] = {static_cast<int>(gi.x), static_cast<int>(gi.y), static_cast<int>(gi.z)};
+  for (int k = 0; k < 3; ++k) vi[k] = std::max(std::min(vi[k], L.vps - 1), 0);
+  *out = blk->voxels[linearIndex(vi[0], vi[1], vi[2], L.vps)];
+  return true;
+}
+// candidate output blocks of transformLayer: input blocks approximated by spheres of diameter sqrt(3) * block_size
+inline std::vector<BIdx> transformCandidateBlocks(const Layer& in, const Transform& T_out_in, float block_size_out) {
+  std::unordered_map<BIdx, int, AnyIndexHash> set;
+  std::vector<BIdx> order;
+  const float kUnitCubeDiagonalLength = static_cast<float>(1.7320508075688772);
+  const float inv = 1.0f / block_size_out;
+  std::vector<BIdx> in_blocks;
+  for (auto& kv : in.blocks) in_blocks.push_back(kv.first);
+  std::sort(in_blocks.begin(), in_blocks.end(), [](const BIdx& a, const BIdx& b) { return std::tie(a.z, a.y, a.x) < std::tie(b.z, b.y, b.x); });
+  for (const BIdx& bi : in_blocks) {
+    const V3 c_in = {centerCoord(bi.x, in.block_size), centerCoord(bi.y, in.block_size), centerCoord(bi.z, in.block_size)};
+    const V3 c_out = transform(T_out_in, c_in);
+    const float offset = static_cast<float>(kUnitCubeDiagonalLength * in.block_size * 0.5);
+    for (float x = c_out.x - offset; x < c_out.x + offset; x += block_size_out)
+      for (float y = c_out.y - offset; y < c_out.y + offset; y += block_size_out)
+        for (float z = c_out.z - offset; z < c_out.z + offset; z += block_size_out) {
+          const BIdx idx = blockIndexFromPoint(V3{x, y, z}, inv);
+          if (set.emplace(idx, 1).second) order.push_back(idx);
+        }
+  }
+  return order;
+}
+inline void transformLayer(const Layer& in, const Transform& T_out_in, Layer* out) {
+  const Transform T_in_out = inverse(T_out_in);
+  for (const BIdx& bi : transformCandidateBlocks(in, T_out_in, out->block_size)) {
+    Block* blk = out->allocateBlock(bi);
+    bool has_data = false;
+    const int nv = out->vps * out->vps * out->vps;
+    for (int lin = 0; lin < nv; ++lin) {
+      const int lx = lin % out->vps, ly = (lin / out->vps) % out->vps, lz = lin / (out->vps * out->vps);
+      const V3 centre = {blk->origin.x + centerCoord(lx, out->voxel_size), blk->origin.y + centerCoord(ly, out->voxel_size),
+                         blk->origin.z + centerCoord(lz, out->voxel_size)};
+      if (resampleVoxel(in, transform(T_in_out, centre), &blk->voxels[lin])) has_data = true;
+    }
+    if (!has_data) out->blocks.erase(bi);
+  }
+}
+inline void mergeLayerAintoLayerB(const Layer& A, Layer* B) {
+  for (auto& kv : A.blocks) {
+    Block* bb = B->allocateBlock(kv.first);
+    for (size_t i = 0; i < bb->voxels.size(); ++i) mergeVoxelAIntoVoxelB(kv.second->voxels[i], &bb->voxels[i]);
+  }
+}
+inline void mergeLayerAintoLayerB(const Layer& A, const Transform& T_B_A, Layer* B) {
+  Layer At(B->voxel_size, B->vps);
+  transformLayer(A, T_B_A, &At);
+  mergeLayerAintoLayerB(At, B);
 }
 
 // ---------------------------------------------------------------------------------------------

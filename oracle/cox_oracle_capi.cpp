@@ -128,6 +128,19 @@ int coxo_layer_upload(coxo_layer* l, const int32_t* idx, const uint32_t* vox, ui
   return COX_OK;
 }
 
+// mergeLayerAintoLayerB(A, [T_B_A,] B): T == nullptr merges on the same grid
+int coxo_layer_merge(const coxo_layer* a, const float T[7], coxo_layer* b) {
+  if (!a || !b) return COX_ERR_INVALID_ARG;
+  if (!T) {
+    if (a->layer.voxel_size != b->layer.voxel_size || a->layer.vps != b->layer.vps) return COX_ERR_INVALID_ARG;
+    mergeLayerAintoLayerB(a->layer, &b->layer);
+  } else {
+    Transform Tr{T[0], T[1], T[2], T[3], {T[4], T[5], T[6]}};
+    mergeLayerAintoLayerB(a->layer, Tr, &b->layer);
+  }
+  return COX_OK;
+}
+
 int coxo_integrator_create(coxo_layer* l, const cox_tsdf_config* cfg, int method, coxo_integrator** out) {
   if (!l || !cfg || !out || method < 0 || method > 2) return COX_ERR_INVALID_ARG;
   auto* h = new coxo_integrator();

@@ -243,3 +243,23 @@ def test_hoisted_reciprocal_division_is_correctly_rounded(hip):
     for seed in (1, 2, 3):
         hip.check(hip.fn("selftest_division")(C.c_int(0), C.c_uint64(1 << 28), C.c_uint64(seed), C.byref(bad)), "selftest_division")
         assert bad.value == 0, bad.value
+
+
+def test_layer_merge_matches_oracle(hip, oracle):
+    """mergeLayerAintoLayerB (map_server.cpp:67-69, submap_collection.cpp:31-33): same grid, and resampled through a rigid
+    transform (trilinear / nearest fallback), on real fused submaps."""
+    out = {}
+    for name, eng in (("hip", hip), ("oracle", oracle)):
+        kw = dict(capacity_blocks=8192) if eng is hip else {}
+        a, _, _ = run_frames(eng, method="merged", voxel=0.10, frames=[0, 10, 20], subsample=5, **kw)
+        b, _, _ = run_frames(eng, method="merged", voxel=0.10, frames=[15, 25], subsample=5, **kw)
+        c, _, _ = run_frames(eng, method="merged", voxel=0.10, frames=[40], subsample=5, **kw)
+        b.merge_from(a)                                   # same grid
+        yaw = np.radians(10.0)
+        T = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), 0.13, -0.07, 0.02], np.float32)
+        c.merge_from(a, T)                                # resampled
+        out[name] = (b, c)
+    for k, what in ((0, "same grid"), (1, "resampled")):
+        rep = compare_layers(out["hip"][k], out["oracle"][k], tol=1e-6)
+        print(what, rep)
+        assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, (what, rep)

@@ -319,3 +319,37 @@ def test_registration_points_of_a_layer(oracle):
     assert layer.registration_points(min_voxel_weight=2.0).shape[0] == 0  # strict >
     rp = RegPoints.from_layer(oracle, layer, 1.0, 0.3)
     assert rp.n == len(pts)
+
+
+def test_layer_merge_same_grid_and_resampled(oracle):
+    """mergeLayerAintoLayerB: same grid -> weights add, distances are the weighted mean; with a transform the source is
+    resampled first -- a linear field shifted by one voxel along x lands one voxel over, exactly."""
+    a = _plane_layer(oracle, voxel=0.1, a=0.05, bx=0.3, by=-0.2, bz=0.1, blocks=((0, 0, 0), (1, 0, 0)))
+    b = _plane_layer(oracle, voxel=0.1, a=0.25, bx=0.3, by=-0.2, bz=0.1, blocks=((0, 0, 0),))
+    b.merge_from(a)
+    idx, vox = b.download()
+    assert [tuple(i) for i in idx] == [(0, 0, 0), (1, 0, 0)]
+    d, w, _ = words_to_fields(vox)
+    da = words_to_fields(a.download()[1])[0]
+    assert np.all(w[0] == 4.0) and np.all(w[1] == 2.0)
+    assert np.allclose(d[0], da[0] + 0.1, atol=1e-6) and np.allclose(d[1], da[1], atol=1e-6)
+    # resample: T_B_A = translation by +0.1 m in x; B's voxel at x sees A's field at x - 0.1
+    c = Layer(oracle, 0.1)
+    T = np.array([1, 0, 0, 0, 0.1, 0, 0], np.float32)
+    c.merge_from(a, T)
+    idx, vox = c.download()
+    d, w, _ = words_to_fields(vox)
+    blocks = {tuple(i): k for k, i in enumerate(idx)}
+    assert (0, 0, 0) in blocks and (1, 0, 0) in blocks
+    lin = np.arange(4096)
+    for bi, k in blocks.items():
+        cx = (bi[0] * 16 + lin % 16 + 0.5) * 0.1 - 0.1
+        cy = (bi[1] * 16 + (lin // 16) % 16 + 0.5) * 0.1
+        cz = (bi[2] * 16 + lin // 256 + 0.5) * 0.1
+        seen = w[k] > 0
+        expect = 0.05 + 0.3 * cx - 0.2 * cy + 0.1 * cz
+        assert np.allclose(d[k][seen], expect[seen], atol=2e-6)
+        assert np.all(w[k][seen] == 2.0)
+    # the source covers x in [0, 3.2): after the shift the first voxel column of block (0,0,0) has no source -> unobserved
+    k0 = blocks[(0, 0, 0)]
+    assert np.all(w[k0][lin % 16 == 0] == 0) and np.all(w[k0][lin % 16 == 1] == 2.0)
