@@ -312,6 +312,126 @@ class Registration:
         return float(ms.value), int(n.value)
 
 
+class MeshMsgStruct(C.Structure):
+    """cox_mesh_msg."""
+    _fields_ = [
+        ("block_edge_length", C.c_float), ("n_blocks", C.c_uint64), ("block_index", C.c_void_p), ("vertex_begin", C.c_void_p),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p),
+        ("block_has_history", C.c_void_p), ("history_begin", C.c_void_p), ("history", C.c_void_p),
+        ("n_poses", C.c_uint64), ("stamp_sec", C.c_void_p), ("stamp_nsec", C.c_void_p), ("T_G_C", C.c_void_p),
+    ]
+
+
+class MeshMsg:
+    """A voxblox_msgs/Mesh with history + trajectory, flattened into the arrays cox_mesh_msg points to.
+
+    blocks: list of dict(index=(ix,iy,iz), x,y,z=uint16[nv], r,g,b=uint8[nv], history=None | list (one per triangle) of
+    run-length lists [first0, last0, first1, last1, ...]); trajectory: list of (sec, nsec, T_G_C[7] float32).
+    """
+
+    def __init__(self, block_edge_length, blocks, trajectory):
+        self.block_edge_length = float(block_edge_length)
+        nb = len(blocks)
+        self.block_index = np.array([b["index"] for b in blocks], np.int64).reshape(nb, 3)
+        counts = [len(b["x"]) for b in blocks]
+        self.vertex_begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(b[k], dt) for b in blocks]) if nb else np.zeros(0, dt), dt)
+        self.x, self.y, self.z = cat("x", np.uint16), cat("y", np.uint16), cat("z", np.uint16)
+        self.r, self.g, self.b = cat("r", np.uint8), cat("g", np.uint8), cat("b", np.uint8)
+        self.block_has_history = np.array([1 if b.get("history") else 0 for b in blocks], np.uint8)
+        hb, hist = [0], []
+        for b, cnt in zip(blocks, counts):
+            runs = b.get("history") or [[] for _ in range(cnt // 3)]
+            assert len(runs) == cnt // 3, "one ObsHistory per triangle"
+            for r in runs:
+                hist.extend(int(v) for v in r)
+                hb.append(len(hist))
+        self.history_begin = np.array(hb, np.uint64)
+        self.history = np.array(hist, np.uint32)
+        self.stamp_sec = np.array([p[0] for p in trajectory], np.uint32)
+        self.stamp_nsec = np.array([p[1] for p in trajectory], np.uint32)
+        self.T_G_C = np.ascontiguousarray(np.array([p[2] for p in trajectory], np.float32).reshape(len(trajectory), 7))
+        self.n_blocks, self.n_poses = nb, len(trajectory)
+
+    def struct(self):
+        m = MeshMsgStruct()
+        m.block_edge_length, m.n_blocks, m.n_poses = self.block_edge_length, self.n_blocks, self.n_poses
+        for k in ("block_index", "vertex_begin", "x", "y", "z", "r", "g", "b", "block_has_history", "history_begin", "history", "stamp_sec",
+                  "stamp_nsec", "T_G_C"):
+            setattr(m, k, getattr(self, k).ctypes.data)
+        return m
+
+
+class MeshConverter:
+    """voxblox::MeshConverter (cox_meshconv_t): recover mode's mesh -> per-pose point clouds."""
+
+    def __init__(self, eng, interpolate_voxel_size=0.2, device=0):
+        self.eng = eng
+        self.h = C.c_void_p()
+        eng.check(eng.fn("meshconv_create")(C.c_int(device), C.c_float(interpolate_voxel_size), C.byref(self.h)), "meshconv_create")
+
+    def close(self):
+        if self.h:
+            self.eng.fn("meshconv_destroy", None)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mesh(self, mesh):
+        m = mesh.struct()
+        self.eng.check(self.eng.fn("meshconv_set_mesh")(self.h, C.byref(m)), "meshconv_set_mesh")
+
+    def convert(self):
+        """convertToPointCloud -> (converted?, recovered xyz float32[n,3], recovered rgb uint8[n,3])."""
+        n, ok = C.c_uint64(), C.c_int()
+        self.eng.check(self.eng.fn("meshconv_convert")(self.h, C.byref(n), C.byref(ok)), "meshconv_convert")
+        return bool(ok.value), *self.recovered()
+
+    def recovered(self):
+        n = C.c_uint64()
+        f = self.eng.fn("meshconv_recovered")
+        self.eng.check(f(self.h, None, None, C.c_uint64(0), C.byref(n)), "meshconv_recovered(query)")
+        xyz = np.zeros((int(n.value), 3), np.float32)
+        rgb = np.zeros((int(n.value), 3), np.uint8)
+        if n.value:
+            self.eng.check(f(self.h, _fp(xyz), _fp(rgb), C.c_uint64(n.value), C.byref(n)), "meshconv_recovered")
+        return xyz, rgb
+
+    def pose_clouds(self):
+        """The sequence getNextPointcloud yields: list of (T_G_C float32[7], points_C float32[n,3], colors uint8[n,4])."""
+        out = []
+        i = C.c_int32(0)
+        T = np.zeros(7, np.float32)
+        n, more = C.c_uint64(), C.c_int()
+        nxt, dl = self.eng.fn("meshconv_next"), self.eng.fn("meshconv_download")
+        while True:
+            k = int(i.value)
+            px, pc = C.c_void_p(), C.c_void_p()
+            self.eng.check(nxt(self.h, C.byref(i), _fp(T), C.byref(px), C.byref(pc), C.byref(n), C.byref(more)), "meshconv_next")
+            if not more.value:
+                break
+            xyz = np.zeros((int(n.value), 3), np.float32)
+            rgba = np.zeros((int(n.value), 4), np.uint8)
+            if n.value:
+                self.eng.check(dl(self.h, C.c_int32(k), _fp(xyz), _fp(rgba), C.c_uint64(n.value), C.byref(n)), "meshconv_download")
+            out.append((T.copy(), xyz, rgba))
+        return out
+
+    def clear(self):
+        self.eng.check(self.eng.fn("meshconv_clear")(self.h), "meshconv_clear")
+
+    def process_mesh(self, integrator, mesh):
+        """TsdfRecover::processMesh up to the serialisation: -> (n_recovered_points, n_integratePointCloud_calls)."""
+        m = mesh.struct()
+        nr, ni = C.c_uint64(), C.c_uint64()
+        self.eng.check(self.eng.fn("recover_process_mesh")(self.h, integrator.h, C.byref(m), C.byref(nr), C.byref(ni)), "recover_process_mesh")
+        return int(nr.value), int(ni.value)
+
+
 # ---- wire-format helpers (voxblox_msgs/Block data words) -----------------------------------------
 def words_to_fields(vox):
     """uint32[...,3] wire words -> (distance f32, weight f32, rgba u8[...,4])."""

@@ -1656,6 +1656,8 @@ static int integrator_finish(cox_integrator* I) {
   return err_bits_to_status(lerr);
 }
 
+cox_layer* cox_internal_integrator_layer(cox_integrator_t* integ) { return integ->layer; }
+
 extern "C" {
 
 int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out) {

@@ -74,3 +74,6 @@ static inline void cox_clear_stale_hip_error(const char* where) {
   }
 }
 #define COX_ENTRY() cox_clear_stale_hip_error(__func__)
+
+// the layer an integrator writes to (cox_integrator is private to cox_integrator.hip)
+cox_layer* cox_internal_integrator_layer(cox_integrator_t* integ);

@@ -48,7 +48,7 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* total, u32* lds 
 }
 
 // n = *d_n if d_n != nullptr else n_max; grid-strides over tiles, so any grid size is correct
-__global__ void __launch_bounds__(kScanThreads) k_scan_blocks(const u32* __restrict__ in, u32* __restrict__ out, u32* __restrict__ block_sums,
+static __global__ void __launch_bounds__(kScanThreads) k_scan_blocks(const u32* __restrict__ in, u32* __restrict__ out, u32* __restrict__ block_sums,
                                                               const u32* __restrict__ d_n, u32 n_max) {
   __shared__ u32 lds[4];
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_blocks(const u32* __restr
   }
 }
 // single block: exclusive scan of the tile sums in place; writes the grand total to *d_total
-__global__ void __launch_bounds__(1024) k_scan_sums(u32* __restrict__ block_sums, const u32* __restrict__ d_n, u32 n_max, u32* __restrict__ d_total) {
+static __global__ void __launch_bounds__(1024) k_scan_sums(u32* __restrict__ block_sums, const u32* __restrict__ d_n, u32 n_max, u32* __restrict__ d_total) {
   __shared__ u32 lds[16];
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 n_tiles = (n + kScanTile - 1) / kScanTile;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(1024) k_scan_sums(u32* __restrict__ block_sums
   }
   if (threadIdx.x == 0 && d_total) *d_total = carry;
 }
-__global__ void __launch_bounds__(kScanThreads) k_scan_add(u32* __restrict__ out, const u32* __restrict__ block_sums, const u32* __restrict__ d_n,
+static __global__ void __launch_bounds__(kScanThreads) k_scan_add(u32* __restrict__ out, const u32* __restrict__ block_sums, const u32* __restrict__ d_n,
                                                            u32 n_max) {
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 n_tiles = (n + kScanTile - 1) / kScanTile;

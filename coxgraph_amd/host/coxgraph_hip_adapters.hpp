@@ -170,6 +170,126 @@ class TsdfIntegrator {
   cox_integrator_t* h_ = nullptr;
 };
 
+// ---- recover mode ---------------------------------------------------------------------------------------------------
+// voxblox_msgs/Mesh (+ history, + trajectory) the way recover mode receives it (mesh_converter.h:55-72)
+struct MeshBlockMsg {
+  int64_t index[3];
+  std::vector<uint16_t> x, y, z;
+  std::vector<uint8_t> r, g, b;
+  std::vector<std::vector<uint32_t>> history;  // voxblox_msgs/ObsHistory per triangle; empty = block skipped
+};
+struct StampedTransformation {
+  uint32_t sec = 0, nsec = 0;  // header.stamp
+  Transformation T_G_C;        // pose after tf::poseMsgToKindr(...).cast<float>()
+};
+struct MeshMsg {
+  float block_edge_length = 0.0f;
+  std::vector<MeshBlockMsg> mesh_blocks;
+  std::vector<StampedTransformation> trajectory;
+};
+struct PointXYZRGB {
+  float x, y, z;
+  uint8_t r, g, b;
+};
+
+// voxblox::MeshConverter (mesh_converter.h:22-289); clouds stay on the GPU
+class MeshConverter {
+ public:
+  explicit MeshConverter(float interpolate_voxel_size = 0.20f, int device = 0) { check(cox_meshconv_create(device, interpolate_voxel_size, &h_), "MeshConverter"); }
+  ~MeshConverter() { cox_meshconv_destroy(h_); }
+  MeshConverter(const MeshConverter&) = delete;
+  MeshConverter& operator=(const MeshConverter&) = delete;
+  void setMesh(const MeshMsg& mesh) {
+    Flat f(mesh);
+    check(cox_meshconv_set_mesh(h_, &f.msg), "setMesh");
+  }
+  bool convertToPointCloud(std::vector<PointXYZRGB>* recovered_pointcloud) {
+    uint64_t n = 0;
+    int converted = 0;
+    check(cox_meshconv_convert(h_, &n, &converted), "convertToPointCloud");
+    fetchRecovered(recovered_pointcloud);
+    return converted != 0;
+  }
+  // device-side variant of getNextPointcloud: the cloud is handed over as device pointers
+  bool getNextPointcloud(int* i, Transformation* T_G_C, const float** points_C_dev, const uint8_t** colors_dev, uint64_t* n) {
+    float T[7];
+    int has_next = 0;
+    int32_t ii = *i;
+    check(cox_meshconv_next(h_, &ii, T, points_C_dev, colors_dev, n, &has_next), "getNextPointcloud");
+    if (!has_next) return false;
+    *i = ii;
+    for (int k = 0; k < 4; ++k) T_G_C->q[k] = T[k];
+    for (int k = 0; k < 3; ++k) T_G_C->t[k] = T[4 + k];
+    return true;
+  }
+  void clear() { check(cox_meshconv_clear(h_), "clear"); }
+  void fetchRecovered(std::vector<PointXYZRGB>* out) {
+    if (!out) return;
+    uint64_t n = 0;
+    check(cox_meshconv_recovered(h_, nullptr, nullptr, 0, &n), "recovered");
+    std::vector<float> xyz(3 * n);
+    std::vector<uint8_t> rgb(3 * n);
+    if (n) check(cox_meshconv_recovered(h_, xyz.data(), rgb.data(), n, &n), "recovered");
+    out->resize(n);
+    for (uint64_t k = 0; k < n; ++k) (*out)[k] = PointXYZRGB{xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]};
+  }
+  cox_meshconv_t* handle() const { return h_; }
+
+  // flattened view of a MeshMsg for the C ABI
+  struct Flat {
+    std::vector<int64_t> index;
+    std::vector<uint64_t> vertex_begin, history_begin;
+    std::vector<uint16_t> x, y, z;
+    std::vector<uint8_t> r, g, b, has;
+    std::vector<uint32_t> history, sec, nsec;
+    std::vector<float> T;
+    cox_mesh_msg msg;
+    explicit Flat(const MeshMsg& m) {
+      vertex_begin.push_back(0);
+      history_begin.push_back(0);
+      for (const MeshBlockMsg& mb : m.mesh_blocks) {
+        if (mb.x.size() % 3 || (!mb.history.empty() && mb.history.size() != mb.x.size() / 3)) throw std::runtime_error("MeshConverter: x.size() / 3 != history.size()");
+        index.insert(index.end(), mb.index, mb.index + 3);
+        x.insert(x.end(), mb.x.begin(), mb.x.end()), y.insert(y.end(), mb.y.begin(), mb.y.end()), z.insert(z.end(), mb.z.begin(), mb.z.end());
+        r.insert(r.end(), mb.r.begin(), mb.r.end()), g.insert(g.end(), mb.g.begin(), mb.g.end()), b.insert(b.end(), mb.b.begin(), mb.b.end());
+        vertex_begin.push_back(x.size());
+        has.push_back(mb.history.empty() ? 0 : 1);
+        for (size_t t = 0; t < mb.x.size() / 3; ++t) {
+          if (!mb.history.empty()) history.insert(history.end(), mb.history[t].begin(), mb.history[t].end());
+          history_begin.push_back(history.size());
+        }
+      }
+      for (const StampedTransformation& p : m.trajectory) {
+        sec.push_back(p.sec), nsec.push_back(p.nsec);
+        float t7[7];
+        p.T_G_C.pack(t7);
+        T.insert(T.end(), t7, t7 + 7);
+      }
+      msg.block_edge_length = m.block_edge_length;
+      msg.n_blocks = m.mesh_blocks.size();
+      msg.block_index = index.data(), msg.vertex_begin = vertex_begin.data();
+      msg.x = x.data(), msg.y = y.data(), msg.z = z.data(), msg.r = r.data(), msg.g = g.data(), msg.b = b.data();
+      msg.block_has_history = has.data(), msg.history_begin = history_begin.data(), msg.history = history.data();
+      msg.n_poses = m.trajectory.size();
+      msg.stamp_sec = sec.data(), msg.stamp_nsec = nsec.data(), msg.T_G_C = T.data();
+    }
+  };
+
+ private:
+  cox_meshconv_t* h_ = nullptr;
+};
+
+// TsdfRecover::processMesh(mesh_msg, &layer_msg, &recovered_pointcloud)  (tsdf_recover.h:59-99)
+inline void processMesh(MeshConverter* mesh_converter, TsdfIntegrator* tsdf_integrator, TsdfLayer* layer, const MeshMsg& mesh_msg, LayerMsg* layer_msg,
+                        std::vector<PointXYZRGB>* recovered_pointcloud) {
+  MeshConverter::Flat f(mesh_msg);
+  uint64_t n_rec = 0, n_int = 0;
+  check(cox_recover_process_mesh(mesh_converter->handle(), tsdf_integrator->handle(), &f.msg, &n_rec, &n_int), "processMesh");
+  mesh_converter->fetchRecovered(recovered_pointcloud);
+  if (layer_msg) serializeLayerAsMsg(*layer, false, layer_msg);
+}
+
+
 // voxgraph::RegistrationPoint
 struct RegistrationPoint {
   float position[3];

@@ -140,3 +140,51 @@ def make_frame(t, client=0, n_clients=1, w=640, h=480, noise=False, nan_fraction
     rgba = frame_colors(w, h)
     keep = np.isfinite(depth.reshape(-1)) & (depth.reshape(-1) > 0)
     return T, np.ascontiguousarray(pts[keep]), np.ascontiguousarray(rgba[keep]), depth
+
+
+def make_wall_mesh(seed=0, n_frames=12, voxel_size=0.05, quads=4, stamp0=(1600000000, 950000000), frame_step=1):
+    """A voxblox_msgs/Mesh-with-history of the room's x = +3.0 m wall region, as recover mode receives it.
+
+    -> dict(block_edge_length, blocks=[...], trajectory=[(sec, nsec, T_G_C float32[7]), ...]) in the form
+    coxgraph_amd.capi.MeshMsg takes.  Blocks are 16 voxels wide; every block holds quads x quads quads (two
+    triangles each) with a little depth jitter and random colours; every triangle carries a run-length observation
+    history over frame ids 0..n_frames-1 (one or two inclusive runs); one block arrives without history (the
+    reference skips such blocks) and one triangle has an empty history.  Poses are the benchmark trajectory's
+    (client 0), stamped 0.05 s * frame_step apart across a second boundary.
+    """
+    rng = np.random.default_rng(seed)
+    edge = 16 * voxel_size
+    ix = int(math.floor(3.0 / edge))
+    blocks = []
+    iy_range = range(int(math.floor(-1.6 / edge)), int(math.floor(1.6 / edge)) + 1)
+    iz_range = range(0, int(math.floor(2.4 / edge)) + 1)
+    for bi, (iy, iz) in enumerate((a, b) for a in iy_range for b in iz_range):
+        # vertex grid in block-local fixed point: value * 2 / 65535 = fraction of the block edge
+        g = np.linspace(0.0, 1.0, quads + 1)
+        depth = (3.0 - ix * edge) / edge + rng.uniform(-0.02, 0.02, (quads + 1, quads + 1))
+        to_u16 = lambda f: np.clip(np.round(f * 65535.0 / 2.0), 0, 65535).astype(np.uint16)
+        vx, vy, vz = to_u16(depth), to_u16(np.broadcast_to(g[:, None], depth.shape)), to_u16(np.broadcast_to(g[None, :], depth.shape))
+        col = rng.integers(0, 256, (quads + 1, quads + 1, 3)).astype(np.uint8)
+        x, y, z, r, gg, b, hist = [], [], [], [], [], [], []
+        for a in range(quads):
+            for c in range(quads):
+                for tri in (((a, c), (a + 1, c), (a, c + 1)), ((a + 1, c), (a + 1, c + 1), (a, c + 1))):
+                    for (p, q) in tri:
+                        x.append(vx[p, q]), y.append(vy[p, q]), z.append(vz[p, q])
+                        r.append(col[p, q, 0]), gg.append(col[p, q, 1]), b.append(col[p, q, 2])
+                    f0 = int(rng.integers(0, n_frames))
+                    f1 = int(rng.integers(f0, n_frames))
+                    runs = [f0, f1]
+                    if f1 + 2 < n_frames and rng.random() < 0.3:
+                        f2 = int(rng.integers(f1 + 2, n_frames))
+                        runs += [f2, int(rng.integers(f2, n_frames))]
+                    hist.append(runs)
+        if bi == 2:
+            hist[5] = []     # a triangle nobody observed
+        blocks.append(dict(index=(ix, iy, iz), x=x, y=y, z=z, r=r, g=gg, b=b, history=None if bi == 1 else hist))
+    sec0, nsec0 = stamp0
+    traj = []
+    for k in range(n_frames):
+        ns = nsec0 + 50000000 * frame_step * k
+        traj.append((sec0 + ns // 1000000000, ns % 1000000000, camera_pose(10 * k)[2]))
+    return dict(block_edge_length=np.float32(edge), blocks=blocks, trajectory=traj)

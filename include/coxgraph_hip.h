@@ -193,6 +193,57 @@ int cox_reg_normal_eq(cox_reg_t* reg, const double pose_ref[4], const double pos
 /* HIP-event time of the registration kernel since last reset (bench.py) */
 int cox_reg_kernel_time(cox_reg_t* reg, double* ms, uint64_t* launches, int reset);
 
+/* ---- recover mode: mesh-with-history -> per-pose point clouds -> integrator ------------------ */
+/* voxblox::MeshConverter (coxgraph/include/coxgraph/map_comm/mesh_converter.h:22-289), the front end of the only
+ * in-tree integrator call (TsdfRecover::processMesh, map_comm/tsdf_recover.h:59-99).  A voxblox_msgs/Mesh with
+ * per-triangle observation history and the client's trajectory, flattened: */
+typedef struct cox_mesh_msg {
+  float block_edge_length;          /* Mesh.block_edge_length */
+  uint64_t n_blocks;                /* Mesh.mesh_blocks.size() */
+  const int64_t* block_index;       /* 3 per block: MeshBlock.index */
+  const uint64_t* vertex_begin;     /* n_blocks+1: block b owns vertices [vertex_begin[b], vertex_begin[b+1]); every
+                                     * count must be a multiple of 3 (the reference CHECKs x.size()/3 == history.size()) */
+  const uint16_t *x, *y, *z;        /* MeshBlock.x/y/z, fixed point in units of 2*block_edge_length/65535 */
+  const uint8_t *r, *g, *b;         /* MeshBlock.r/g/b */
+  const uint8_t* block_has_history; /* n_blocks: 0 = MeshBlock.history.empty() -> block skipped (mesh_converter.h:87) */
+  const uint64_t* history_begin;    /* n_vertices/3 + 1: triangle t (global vertex index / 3) owns history[begin[t], begin[t+1]) */
+  const uint32_t* history;          /* ObsHistory.history: inclusive [first, last] frame-id runs, even length */
+  uint64_t n_poses;                 /* Mesh.trajectory.poses.size() */
+  const uint32_t* stamp_sec;        /* PoseStamped.header.stamp */
+  const uint32_t* stamp_nsec;
+  const float* T_G_C;               /* 7 per pose (qw qx qy qz tx ty tz): the pose after tf::poseMsgToKindr + cast<float>
+                                     * (mesh_converter.h:64-69; that conversion is minkindr's and stays with the caller) */
+} cox_mesh_msg;
+
+typedef struct cox_meshconv cox_meshconv_t;
+/* MeshConverter(nh_private): interpolate_voxel_size is the rosparam of mesh_converter.h:36-41 (default 0.20) */
+int cox_meshconv_create(int device, float interpolate_voxel_size, cox_meshconv_t** out);
+void cox_meshconv_destroy(cox_meshconv_t* conv);
+/* setMesh(mesh) + setTrajectory(mesh.trajectory)  (mesh_converter.h:55-72): uploads the message. A mesh with an empty
+ * trajectory is ignored like the reference does (returns COX_OK, nothing stored). */
+int cox_meshconv_set_mesh(cox_meshconv_t* conv, const cox_mesh_msg* mesh);
+/* convertToPointCloud(&recovered_pointcloud)  (mesh_converter.h:74-168): decodes the vertices, interpolates every
+ * triangle (interpolateTriangle, :212-277), expands the run-length histories and builds one cloud per frame id
+ * (uint8 key, as the reference's std::map<uint8_t,...>) in HBM; also transforms each pose's cloud into its camera frame
+ * (what getNextPointcloud does per call).  *converted = 0 when the mesh has no blocks (the reference returns false). */
+int cox_meshconv_convert(cox_meshconv_t* conv, uint64_t* n_recovered_points, int* converted);
+/* the recovered_pointcloud of convertToPointCloud (one XYZRGB point per mesh vertex of blocks with history): n*3 floats, n*3 bytes */
+int cox_meshconv_recovered(cox_meshconv_t* conv, float* xyz, uint8_t* rgb, uint64_t cap, uint64_t* n);
+/* getNextPointcloud(&i, &T_G_C, &points_C, &colors)  (mesh_converter.h:183-210): device pointers to pose *i's cloud in
+ * the camera frame (valid until set_mesh/clear/destroy), *i is advanced; *has_next = 0 when *i is past the trajectory */
+int cox_meshconv_next(cox_meshconv_t* conv, int32_t* i, float T_G_C[7], const float** xyz_dev, const uint8_t** rgba_dev, uint64_t* n,
+                      int* has_next);
+/* host copy of pose i's cloud (tests): does not advance anything */
+int cox_meshconv_download(cox_meshconv_t* conv, int32_t i, float* xyz, uint8_t* rgba, uint64_t cap, uint64_t* n);
+/* clear()  (mesh_converter.h:170-181) */
+int cox_meshconv_clear(cox_meshconv_t* conv);
+/* TsdfRecover::processMesh(mesh_msg, &layer_msg, &recovered_pointcloud)  (tsdf_recover.h:59-99) up to the
+ * serialisation: removeAllBlocks, setMesh, convertToPointCloud, then one integratePointCloud(T_G_C, points_C, colors,
+ * false) per pose with a non-empty cloud, clear().  Everything stays on the GPU; the layer is then read with
+ * cox_layer_download.  n_integrated = number of integratePointCloud calls made. */
+int cox_recover_process_mesh(cox_meshconv_t* conv, cox_integrator_t* integ, const cox_mesh_msg* mesh, uint64_t* n_recovered_points,
+                             uint64_t* n_integrated);
+
 #ifdef __cplusplus
 }
 #endif

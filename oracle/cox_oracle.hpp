@@ -361,6 +361,8 @@ class Integrator {
     last_stats = stats_;
   }
 
+ Layer* layer() const { return layer_; }
+
  private:
   Layer* layer_;
   TsdfConfig cfg_;

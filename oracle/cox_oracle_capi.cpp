@@ -5,6 +5,7 @@
 // Python wrapper.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this.
 #include "../include/coxgraph_hip.h"
 #include "cox_oracle.hpp"
+#include "cox_oracle_mesh.hpp"
 
 #include <map>
 #include <tuple>
@@ -338,4 +339,134 @@ int coxo_reg_normal_eq(coxo_reg* reg, const double pose_ref[4], const double pos
   return regRun(reg, pose_ref, pose_read, sample_idx, n_res, nullptr, nullptr, nullptr, H, b, cost, n_corr);
 }
 
+}  // extern "C"
+
+// ---- recover mode: MeshConverter + processMesh (cox_oracle_mesh.hpp) ----------------------------------------------------
+struct coxo_meshconv {
+  MeshConverter conv;
+  std::vector<RecoveredPoint> recovered;
+  std::vector<V3> cur_pts;
+  std::vector<Color> cur_colors;
+  explicit coxo_meshconv(float vs) : conv(vs) {}
+};
+static int toMeshMsg(const cox_mesh_msg* m, MeshMsg* out) {
+  if (!m) return COX_ERR_INVALID_ARG;
+  out->block_edge_length = m->block_edge_length;
+  out->mesh_blocks.resize(m->n_blocks);
+  for (uint64_t b = 0; b < m->n_blocks; ++b) {
+    MeshBlockMsg& mb = out->mesh_blocks[b];
+    for (int k = 0; k < 3; ++k) mb.index[k] = m->block_index[3 * b + k];
+    const uint64_t v0 = m->vertex_begin[b], v1 = m->vertex_begin[b + 1];
+    if (v1 < v0 || v0 % 3 || v1 % 3) return COX_ERR_INVALID_ARG;
+    mb.x.assign(m->x + v0, m->x + v1);
+    mb.y.assign(m->y + v0, m->y + v1);
+    mb.z.assign(m->z + v0, m->z + v1);
+    mb.r.assign(m->r + v0, m->r + v1);
+    mb.g.assign(m->g + v0, m->g + v1);
+    mb.b.assign(m->b + v0, m->b + v1);
+    if (m->block_has_history[b]) {
+      for (uint64_t t = v0 / 3; t < v1 / 3; ++t) {
+        const uint64_t h0 = m->history_begin[t], h1 = m->history_begin[t + 1];
+        if (h1 < h0 || (h1 - h0) % 2) return COX_ERR_INVALID_ARG;
+        mb.history.emplace_back(m->history + h0, m->history + h1);
+      }
+    }
+  }
+  for (uint64_t i = 0; i < m->n_poses; ++i) {
+    const float* T = m->T_G_C + 7 * i;
+    out->trajectory.push_back({m->stamp_sec[i], m->stamp_nsec[i], Transform{T[0], T[1], T[2], T[3], {T[4], T[5], T[6]}}});
+  }
+  return COX_OK;
+}
+
+extern "C" {
+int coxo_meshconv_create(int, float interpolate_voxel_size, coxo_meshconv** out) {
+  if (!out || !(interpolate_voxel_size > 0.0f)) return COX_ERR_INVALID_ARG;
+  *out = new coxo_meshconv(interpolate_voxel_size);
+  return COX_OK;
+}
+void coxo_meshconv_destroy(coxo_meshconv* c) { delete c; }
+int coxo_meshconv_set_mesh(coxo_meshconv* c, const cox_mesh_msg* mesh) {
+  if (!c) return COX_ERR_INVALID_ARG;
+  MeshMsg m;
+  const int rc = toMeshMsg(mesh, &m);
+  if (rc != COX_OK) return rc;
+  c->conv.setMesh(m);
+  return COX_OK;
+}
+int coxo_meshconv_convert(coxo_meshconv* c, uint64_t* n_recovered, int* converted) {
+  if (!c) return COX_ERR_INVALID_ARG;
+  const bool ok = c->conv.convertToPointCloud(&c->recovered);
+  if (n_recovered) *n_recovered = c->recovered.size();
+  if (converted) *converted = ok ? 1 : 0;
+  return COX_OK;
+}
+int coxo_meshconv_recovered(coxo_meshconv* c, float* xyz, uint8_t* rgb, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return COX_ERR_INVALID_ARG;
+  *n = c->recovered.size();
+  if (!xyz && !rgb) return COX_OK;
+  if (cap < *n) return COX_ERR_BUFFER_TOO_SMALL;
+  for (size_t i = 0; i < c->recovered.size(); ++i) {
+    const RecoveredPoint& p = c->recovered[i];
+    if (xyz) xyz[3 * i] = p.x, xyz[3 * i + 1] = p.y, xyz[3 * i + 2] = p.z;
+    if (rgb) rgb[3 * i] = p.r, rgb[3 * i + 1] = p.g, rgb[3 * i + 2] = p.b;
+  }
+  return COX_OK;
+}
+// pose i's cloud as getNextPointcloud would yield it (i is not advanced here)
+static bool meshconvCloud(coxo_meshconv* c, int32_t i, Transform* T, std::vector<V3>* pts, std::vector<Color>* colors) {
+  int ii = i;
+  return c->conv.getNextPointcloud(&ii, T, pts, colors);
+}
+// "device" pointers are host pointers here (valid until the next call on this handle)
+int coxo_meshconv_next(coxo_meshconv* c, int32_t* i, float T_G_C[7], const float** xyz, const uint8_t** rgba, uint64_t* n, int* has_next) {
+  if (!c || !i || !n || !has_next) return COX_ERR_INVALID_ARG;
+  Transform T;
+  *n = 0;
+  if (!meshconvCloud(c, *i, &T, &c->cur_pts, &c->cur_colors)) {
+    *has_next = 0;
+    return COX_OK;
+  }
+  *has_next = 1;
+  *n = c->cur_pts.size();
+  if (T_G_C) {
+    T_G_C[0] = T.qw, T_G_C[1] = T.qx, T_G_C[2] = T.qy, T_G_C[3] = T.qz;
+    T_G_C[4] = T.t.x, T_G_C[5] = T.t.y, T_G_C[6] = T.t.z;
+  }
+  if (xyz) *xyz = c->cur_pts.empty() ? nullptr : &c->cur_pts[0].x;
+  if (rgba) *rgba = c->cur_colors.empty() ? nullptr : &c->cur_colors[0].r;
+  ++*i;
+  return COX_OK;
+}
+int coxo_meshconv_download(coxo_meshconv* c, int32_t i, float* xyz, uint8_t* rgba, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return COX_ERR_INVALID_ARG;
+  Transform T;
+  std::vector<V3> pts;
+  std::vector<Color> colors;
+  if (!meshconvCloud(c, i, &T, &pts, &colors)) return COX_ERR_INVALID_ARG;
+  *n = pts.size();
+  if (!xyz && !rgba) return COX_OK;
+  if (cap < pts.size()) return COX_ERR_BUFFER_TOO_SMALL;
+  for (size_t k = 0; k < pts.size(); ++k) {
+    if (xyz) xyz[3 * k] = pts[k].x, xyz[3 * k + 1] = pts[k].y, xyz[3 * k + 2] = pts[k].z;
+    if (rgba) rgba[4 * k] = colors[k].r, rgba[4 * k + 1] = colors[k].g, rgba[4 * k + 2] = colors[k].b, rgba[4 * k + 3] = colors[k].a;
+  }
+  return COX_OK;
+}
+int coxo_meshconv_clear(coxo_meshconv* c) {
+  if (!c) return COX_ERR_INVALID_ARG;
+  c->conv.clear();  // the caller's recovered_pointcloud is not touched by clear()
+  return COX_OK;
+}
+int coxo_recover_process_mesh(coxo_meshconv* c, coxo_integrator* integ, const cox_mesh_msg* mesh, uint64_t* n_recovered, uint64_t* n_integrated) {
+  if (!c || !integ) return COX_ERR_INVALID_ARG;
+  MeshMsg m;
+  const int rc = toMeshMsg(mesh, &m);
+  if (rc != COX_OK) return rc;
+  size_t ni = 0;
+  processMesh(&c->conv, integ->integ.get(), integ->integ->layer(), m, &c->recovered, &ni);
+  if (n_recovered) *n_recovered = c->recovered.size();
+  if (n_integrated) *n_integrated = ni;
+  return COX_OK;
+}
 }  // extern "C"
