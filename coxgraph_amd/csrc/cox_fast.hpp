@@ -1,0 +1,289 @@
+// voxblox FastTsdfIntegrator on the GPU, reproducing the reference's result at integrator_threads = 1.
+// Included by cox_integrator.hip (uses its RayArrays / Counters / helpers).
+//
+// The reference walks the points one after the other (mixed order) and keeps two lossy sets
+// (ApproxHashSet<20, 10000, GlobalIndex, LongIndexHash>: 2^20 slots, slot = hash & mask, "replaceHash" returns
+// whether the slot held another value and stores the new one):
+//   * start set: a point whose half-voxel cell's hash is already in its slot is skipped;
+//   * observed set: a ray walks from the surface towards the sensor; a voxel whose hash is already in its slot counts
+//     as a collision; after more than max_consecutive_ray_collisions collisions in a row the ray stops.
+// Both are "last writer wins" tables, so what an operation sees is the hash of the PREVIOUS OPERATION ON ITS SLOT in
+// visiting order (or what earlier frames left there).  That makes the sequential algorithm a sort problem:
+//   start set     every valid point performs its operation whatever the outcome -> sort the points by slot (stable, from
+//                 visiting order), compare each with its predecessor in the slot.  One pass, exact.
+//   observed set  which operations happen depends on where earlier rays stopped.  reach[r] (voxels ray r updates) is the
+//                 unique solution of a triangular system (a ray only depends on lower-numbered rays); it is found by
+//                 Jacobi sweeps: given a guess of every ray's reach, the operations are known; sort all candidate
+//                 visits by slot once per frame, and per sweep (a) prefix-max over "is this visit performed" gives every
+//                 visit the previous performed operation on its slot, (b) every ray re-walks its visits and recomputes
+//                 where it stops.  A sweep that changes nothing has reached the sequential result (15-18 sweeps on the
+//                 benchmark frames; each sweep fixes at least the lowest-numbered wrong ray, so it always terminates).
+// The updates themselves then go through the `simple` pipeline (records sorted by voxel, replayed in visiting order).
+#pragma once
+
+namespace cox {
+
+constexpr u32 kFastSlotBits = 20;
+constexpr u32 kFastSlots = 1u << kFastSlotBits, kFastSlotMask = kFastSlots - 1u;
+constexpr u32 kFastFullReset = 10000;  // ApproxHashSet full_reset_threshold
+constexpr u32 kFastTile = 2048;        // positions per workgroup in the prefix-max
+
+struct FastFrame {  // per-frame constants of the fast integrator
+  u64 off_start, off_obs;  // ApproxHashSet::offset_ of the two sets
+  int max_collisions;
+};
+
+// voxblox LongIndexHash on a GlobalIndex (int64 components), in size_t arithmetic
+__device__ __forceinline__ u64 long_index_hash(int x, int y, int z) {
+  constexpr u64 sl = 17191ull, sl2 = sl * sl;
+  return static_cast<u64>(static_cast<int64_t>(x)) + static_cast<u64>(static_cast<int64_t>(y)) * sl + static_cast<u64>(static_cast<int64_t>(z)) * sl2;
+}
+
+// ---- start set ----------------------------------------------------------------------------------------------------
+// thread = visiting sequence number: the point's start-set hash (hash of its half-voxel cell + offset) and slot
+__global__ void __launch_bounds__(256) k_fast_points(const FrameParams* __restrict__ Pp, FastFrame FF, u64* __restrict__ fhash, u32* __restrict__ skey,
+                                                     u32* __restrict__ sval, Counters* cnt) {
+  const FrameParams P = *Pp;
+  for (u32 seq = blockIdx.x * blockDim.x + threadIdx.x; seq < P.n_points; seq += gridDim.x * blockDim.x) {
+    const u32 idx = mixed_index(seq, P.n_points);
+    const F3 p{P.xyz[3 * idx], P.xyz[3 * idx + 1], P.xyz[3 * idx + 2]};
+    bool clearing = false;
+    bool valid = point_valid(P, p, &clearing);
+    u32 key = kFastSlots;  // sorts behind every slot
+    u64 h = 0;
+    if (valid) {
+      const F3 pg = transform_point(P, p);
+      const float sx = pg.x * P.start_subsampling_inv, sy = pg.y * P.start_subsampling_inv, sz = pg.z * P.start_subsampling_inv;
+      if (!(index_in_range(sx) && index_in_range(sy) && index_in_range(sz))) {
+        atomicOr(&cnt->err, kErrRange);
+        valid = false;
+      } else {
+        h = long_index_hash(grid_index(sx), grid_index(sy), grid_index(sz)) + FF.off_start;
+        key = static_cast<u32>(h) & kFastSlotMask;
+      }
+    }
+    fhash[seq] = h;
+    skey[seq] = key;
+    sval[seq] = seq;
+    const u64 m = __ballot(valid);
+    if (lane_id() == 0 && m) atomicAdd(&cnt->shard[(seq >> 6) & 63u][kShValid], static_cast<u32>(__popcll(m)));
+  }
+}
+// thread = position in the slot-sorted order: fresh = the slot did not hold this hash
+__global__ void __launch_bounds__(256) k_fast_start_flags(const FrameParams* __restrict__ Pp, const u32* __restrict__ skey, const u32* __restrict__ sval,
+                                                          const u64* __restrict__ fhash, const u64* __restrict__ table_start, u32* __restrict__ fresh) {
+  const u32 n = Pp->n_points;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 key = skey[i], seq = sval[i];
+    u32 f = 0;
+    if (key < kFastSlots) {
+      const u64 h = fhash[seq];
+      const u64 prev = (i > 0 && skey[i - 1] == key) ? fhash[sval[i - 1]] : table_start[key];
+      f = (prev != h) ? 1u : 0u;
+    }
+    fresh[seq] = f;
+  }
+}
+// the table keeps the hash of the last operation on each slot
+__global__ void __launch_bounds__(256) k_fast_start_commit(const FrameParams* __restrict__ Pp, const u32* __restrict__ skey, const u32* __restrict__ sval,
+                                                           const u64* __restrict__ fhash, u64* __restrict__ table_start) {
+  const u32 n = Pp->n_points;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 key = skey[i];
+    if (key < kFastSlots && (i + 1 == n || skey[i + 1] != key)) table_start[key] = fhash[sval[i]];
+  }
+}
+// thread = sequence number: the points that start a ray, compacted in visiting order (ray id = rank among them)
+__global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict__ Pp, const u32* __restrict__ fresh, const u32* __restrict__ rank, RayArrays R,
+                                                   Counters* cnt) {
+  const FrameParams P = *Pp;
+  for (u32 seq = blockIdx.x * blockDim.x + threadIdx.x; seq < P.n_points; seq += gridDim.x * blockDim.x) {
+    if (!fresh[seq]) continue;
+    const u32 r = rank[seq];
+    const u32 idx = mixed_index(seq, P.n_points);
+    const F3 p{P.xyz[3 * idx], P.xyz[3 * idx + 1], P.xyz[3 * idx + 2]};
+    bool clearing = false;
+    (void)point_valid(P, p, &clearing);
+    const F3 pg = transform_point(P, p);
+    Dda d;
+    dda_setup(d, P, pg, clearing);  // P.cast_from_origin == 0: from the far end of the ray towards the sensor
+    if (d.range_error) atomicOr(&cnt->err, kErrRange);
+    R.px[r] = pg.x;
+    R.py[r] = pg.y;
+    R.pz[r] = pg.z;
+    R.w[r] = voxel_weight(P, p);
+    R.color[r] = pack_rgba_wire(P.rgba, idx);
+    R.flags[r] = 1u | (clearing ? 2u : 0u);
+    R.nsteps[r] = d.nsteps;  // the whole walk; replaced by the ray's reach once that is known
+  }
+}
+
+// ---- observed set -------------------------------------------------------------------------------------------------
+// thread = ray: every voxel the ray would visit if nothing stopped it, in walking order
+__global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ vhash, u32* __restrict__ vkey,
+                                                     u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ reach, u32 vcap, Counters* cnt) {
+  const FrameParams P = *Pp;
+  const u32 n_rays = cnt->n_rays;
+  const bool overflow = cnt->n_records > vcap;  // cannot happen unless the worst-case bound itself exceeds the 2^31 limit
+  if (overflow && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, kErrRecords);
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
+    if (overflow) {  // the frame is dropped as a whole
+      R.nsteps[r] = 0;
+      reach[r] = 0;
+      continue;
+    }
+    const u32 ns = R.nsteps[r];
+    reach[r] = ns;
+    if (ns == 0) continue;
+    const u32 off = R.rec_off[r];
+    const F3 pg{R.px[r], R.py[r], R.pz[r]};
+    Dda d;
+    dda_setup(d, P, pg, (R.flags[r] & 2u) != 0);
+    for (u32 s = 0; s < ns; ++s) {
+      const u64 h = long_index_hash(d.c[0], d.c[1], d.c[2]) + FF.off_obs;
+      dda_step(d);
+      vhash[off + s] = h;
+      vkey[off + s] = static_cast<u32>(h) & kFastSlotMask;
+      vval[off + s] = off + s;
+      vray[off + s] = r;
+    }
+  }
+}
+// visits of the frame (0 when the frame was dropped for overflowing the visit buffers)
+__device__ __forceinline__ u32 fast_num_visits(const Counters* cnt, u32 vcap) { return cnt->n_records > vcap ? 0u : cnt->n_records; }
+// position of every visit in the slot-sorted order
+__global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ vval_sorted, u32* __restrict__ pos_of, const Counters* cnt, u32 vcap) {
+  const u32 n = fast_num_visits(cnt, vcap);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pos_of[vval_sorted[i]] = i;
+}
+
+template <int NW>
+__device__ __forceinline__ u32 block_exclusive_max(u32 v, u32* total, u32* lds /*[NW]*/) {
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 o = static_cast<u32>(__shfl_up(static_cast<int>(inc), off, 64));
+    if (lane >= static_cast<u32>(off)) inc = max(inc, o);
+  }
+  u32 ex = static_cast<u32>(__shfl_up(static_cast<int>(inc), 1, 64));
+  if (lane == 0) ex = 0;
+  __syncthreads();
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (u32 w = 0; w < NW; ++w) {
+    const u32 s = lds[w];
+    if (w < wave) base = max(base, s);
+    tot = max(tot, s);
+  }
+  *total = tot;
+  return max(base, ex);
+}
+
+struct FastVisits {
+  const u32* vkey;   // slot of the visit at sorted position i
+  const u32* vval;   // visit index (ray-major) at sorted position i
+  const u32* vray;   // ray of visit v
+  const u64* vhash;  // hash of visit v
+  const u32* voff;   // first visit of ray r
+  const u32* pos_of;
+};
+// is the visit at sorted position i performed under the current guess?  (steps 0 .. reach, the last one being the
+// operation that made the ray stop; a ray that never stops has reach == its whole walk)
+__device__ __forceinline__ bool fast_active(const FastVisits& V, const u32* __restrict__ reach, u32 i) {
+  const u32 v = V.vval[i];
+  const u32 r = V.vray[v];
+  return v - V.voff[r] <= reach[r];
+}
+// sweep, part 1: eloc[i] = 1 + the last performed position before i inside i's tile (0 = none), tmax[tile] = same over the tile
+__global__ void __launch_bounds__(256) k_fast_scan_tiles(FastVisits V, const u32* __restrict__ reach, u32* __restrict__ eloc, u32* __restrict__ tmax,
+                                                         const Counters* cnt, u32 vcap) {
+  __shared__ u32 lds[4];
+  const u32 n = fast_num_visits(cnt, vcap);
+  const u32 n_tiles = (n + kFastTile - 1) / kFastTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const u32 base = tile * kFastTile + threadIdx.x * 8;
+    u32 a[8], mx = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const u32 i = base + q;
+      a[q] = (i < n && fast_active(V, reach, i)) ? i + 1 : 0u;
+      mx = max(mx, a[q]);
+    }
+    u32 total;
+    u32 ex = block_exclusive_max<4>(mx, &total, lds);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (base + q < n) eloc[base + q] = ex;
+      ex = max(ex, a[q]);
+    }
+    if (threadIdx.x == 0) tmax[tile] = total;
+  }
+}
+// sweep, part 2 (one workgroup): tcarry[tile] = 1 + last performed position before the tile
+__global__ void __launch_bounds__(1024) k_fast_scan_carry(const u32* __restrict__ tmax, u32* __restrict__ tcarry, const Counters* cnt, u32 vcap) {
+  __shared__ u32 lds[16];
+  const u32 n = fast_num_visits(cnt, vcap);
+  const u32 n_tiles = (n + kFastTile - 1) / kFastTile;
+  u32 carry = 0;
+  for (u32 base = 0; base < n_tiles; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = (i < n_tiles) ? tmax[i] : 0u;
+    u32 total;
+    const u32 ex = block_exclusive_max<16>(v, &total, lds);
+    if (i < n_tiles) tcarry[i] = max(carry, ex);
+    carry = max(carry, total);
+  }
+}
+// was the slot of the visit at position i last written with the same hash?
+__device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tcarry,
+                                               const u64* __restrict__ table_obs, u32 i, u64 h) {
+  const u32 e = max(eloc[i], tcarry[i / kFastTile]);
+  const u32 key = V.vkey[i];
+  const u64 prev = (e > 0 && V.vkey[e - 1] == key) ? V.vhash[V.vval[e - 1]] : table_obs[key];
+  return prev == h;
+}
+// sweep, part 3: thread = ray: walk, count consecutive collisions, stop like the reference does
+__global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, FastFrame FF, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
+                                                    const u32* __restrict__ tcarry, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
+                                                    u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt) {
+  const u32 n_rays = cnt->n_rays;
+  bool any = false;
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
+    const u32 ns = nfull[r], off = V.voff[r];
+    int col = 0;
+    u32 k = 0;
+    for (; k < ns; ++k) {
+      const u32 v = off + k;
+      if (fast_collision(V, eloc, tcarry, table_obs, V.pos_of[v], V.vhash[v])) ++col;
+      else col = 0;
+      if (col > FF.max_collisions) break;
+    }
+    reach_out[r] = k;
+    any |= (k != reach_in[r]);
+  }
+  if (__ballot(any) && lane_id() == 0) atomicOr(changed, 1u);
+}
+// after the last sweep: the table keeps the hash of the last performed operation on each slot
+__global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32* __restrict__ reach, const u32* __restrict__ eloc, const u32* __restrict__ tcarry,
+                                                         u64* __restrict__ table_obs, const Counters* cnt, u32 vcap) {
+  const u32 n = fast_num_visits(cnt, vcap);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 key = V.vkey[i];
+    if (i + 1 < n && V.vkey[i + 1] == key) continue;  // not the end of the slot's run
+    u32 e = max(eloc[i], tcarry[i / kFastTile]);
+    if (fast_active(V, reach, i)) e = i + 1;
+    if (e > 0 && V.vkey[e - 1] == key) table_obs[key] = V.vhash[V.vval[e - 1]];
+  }
+}
+// hand the rays over to the record pipeline: a ray emits its first reach[r] voxels
+__global__ void __launch_bounds__(256) k_fast_finish(RayArrays R, const u32* __restrict__ reach, Counters* cnt) {
+  const u32 n_rays = cnt->n_rays;
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->n_ray_slots = n_rays;
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) R.nsteps[r] = reach[r];
+}
+
+}  // namespace cox

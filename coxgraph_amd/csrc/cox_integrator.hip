@@ -550,6 +550,8 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
   }
 }
 
+#include "cox_fast.hpp"
+
 // ---- wave-per-ray traversal (few, long rays: the merged integrator's bundles) -----------------------------
 // A DDA is a dependent chain, so lane-per-ray leaves the chip empty when a frame has only a few thousand rays.
 // Here one wave walks one ray in parallel and reproduces the sequential argmin walk bit for bit:
@@ -1218,8 +1220,22 @@ struct RecordSet {  // lives B1 .. B2
   bool used = false;
 };
 
+// buffers of the fast integrator (method == COX_METHOD_FAST only); see cox_fast.hpp
+constexpr int kFastMaxSweeps = 512;
+struct FastState {
+  u64 *fhash = nullptr, *vhash = nullptr, *table_start = nullptr, *table_obs = nullptr;
+  u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *tcarry = nullptr;
+  u32* reach[2] = {nullptr, nullptr};
+  u32* d_changed = nullptr;  // [kFastMaxSweeps]
+  u32* h_changed = nullptr;  // pinned mirror
+  u64 off_start = 0, off_obs = 0;  // ApproxHashSet::offset_
+  int reset_counter = 0;
+  uint64_t sweeps_total = 0, frames = 0;
+};
+
 struct cox_integrator {
   cox_layer* layer = nullptr;
+  FastState fast;
   cox_tsdf_config cfg;
   int method = 0;
   hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // stream of stage A1, A2, B1, B2 (st[1] == st[0], st[3] == st[2]: see create)
@@ -1349,6 +1365,20 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&S.piece_wsum, static_cast<size_t>(wave_cap) * 2));
   }
   COX_TRY(alloc_sort_ws(&I->sort_rec, rcap));
+  if (I->method == COX_METHOD_FAST) {
+    FastState& X = I->fast;
+    COX_TRY(dev_realloc(&X.fhash, cap));
+    COX_TRY(dev_realloc(&X.fresh, cap));
+    COX_TRY(dev_realloc(&X.rank, cap));
+    COX_TRY(dev_realloc(&X.reach[0], cap));
+    COX_TRY(dev_realloc(&X.reach[1], cap));
+    COX_TRY(dev_realloc(&X.vhash, rcap));
+    COX_TRY(dev_realloc(&X.vray, rcap));
+    COX_TRY(dev_realloc(&X.pos_of, rcap));
+    COX_TRY(dev_realloc(&X.eloc, rcap));
+    COX_TRY(dev_realloc(&X.tmax, rcap / kFastTile + 2));
+    COX_TRY(dev_realloc(&X.tcarry, rcap / kFastTile + 2));
+  }
   const u32 need_scan = scan_num_blocks(cap) + 2;
   if (need_scan > I->scan_cap) {
     COX_TRY(dev_realloc(&I->scanws_a.block_sums, need_scan));
@@ -1389,7 +1419,7 @@ static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n,
   P.use_sparsity = c.use_sparsity_compensation_factor;
   P.anti_grazing = (I->method == COX_METHOD_MERGED) ? c.enable_anti_grazing : 0;
   P.freespace = freespace;
-  P.cast_from_origin = 1;
+  P.cast_from_origin = (I->method == COX_METHOD_FAST) ? 0 : 1;  // the fast integrator walks from the surface towards the sensor
   P.xyz = xyz;
   P.rgba = rgba;
   P.np2 = next_pow2(static_cast<u64>(n) + 1);
@@ -1562,6 +1592,76 @@ static int run_stage(int k, const StageCtx& c) {
   return COX_OK;
 }
 
+// ---- fast: one frame.  Everything runs on one stream; the relaxation of the early-termination rule (cox_fast.hpp) is
+// checked for convergence from the host every few sweeps, so unlike simple / merged this call is not fully asynchronous.
+static int fast_frame(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  RecordSet& S = *c.S;
+  FastState& X = I->fast;
+  // FastTsdfIntegrator::integratePointCloud: both sets are reset every clear_checks_every_n_frames frames;
+  // ApproxHashSet::resetApproxSet bumps the offset and wipes the table every 10 000 resets
+  if (++X.reset_counter >= I->cfg.clear_checks_every_n_frames) {
+    X.reset_counter = 0;
+    if (++X.off_start >= kFastFullReset) {
+      COX_HIP(hipMemsetAsync(X.table_start, 0, sizeof(u64) * kFastSlots, s));
+      X.off_start = 0;
+    }
+    if (++X.off_obs >= kFastFullReset) {
+      COX_HIP(hipMemsetAsync(X.table_obs, 0, sizeof(u64) * kFastSlots, s));
+      X.off_obs = 0;
+    }
+  }
+  const FastFrame FF{X.off_start, X.off_obs, I->cfg.max_consecutive_ray_collisions};
+  const u32 n = I->pcap, vcap = I->rcap;
+  const dim3 gp = grid_for(n, 256, 4096), gv(2048), gr = grid_for(n, 256, 1024);
+  COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
+  COX_HIP(hipMemsetAsync(X.d_changed, 0, sizeof(u32) * kFastMaxSweeps, s));
+  // start set: sort the points by slot (21 key bits: slot + "not integrated"), compare neighbours
+  hipLaunchKernelGGL(k_fast_points, gp, dim3(256), 0, s, F.d_params, FF, X.fhash, B.skey[0], B.sval[0], F.cnt);
+  const int pp = radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, kFastSlotBits + 1, false, 2, I->sort_pts, nullptr, s);
+  hipLaunchKernelGGL(k_fast_start_flags, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start, X.fresh);
+  hipLaunchKernelGGL(k_fast_start_commit, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start);
+  exclusive_scan_u32(X.fresh, X.rank, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
+  hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, F.cnt);
+  // candidate visits: every voxel of every ray's whole walk, sorted by slot of the observed set
+  exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
+  hipLaunchKernelGGL(k_fast_visits, gr, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
+  const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21), kFastSlotBits,
+                                      false, 2, I->sort_rec, nullptr, s);
+  hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.pos_of, F.cnt, vcap);
+  const FastVisits V{S.rec_key[vp], S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of};
+  // Jacobi sweeps until one changes nothing
+  int sweep = 0, batch = 14;
+  bool converged = false;
+  while (!converged) {
+    if (sweep + batch > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
+    const int first = sweep;
+    for (int k = 0; k < batch; ++k, ++sweep) {
+      hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[sweep & 1], X.eloc, X.tmax, F.cnt, vcap);
+      hipLaunchKernelGGL(k_fast_scan_carry, dim3(1), dim3(1024), 0, s, X.tmax, X.tcarry, F.cnt, vcap);
+      hipLaunchKernelGGL(k_fast_sweep, gr, dim3(256), 0, s, V, FF, F.rays.nsteps, X.eloc, X.tcarry, X.table_obs, X.reach[sweep & 1], X.reach[(sweep + 1) & 1],
+                         X.d_changed + sweep, F.cnt);
+    }
+    COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * batch, hipMemcpyDeviceToHost, s));
+    COX_HIP(hipStreamSynchronize(s));
+    converged = X.h_changed[sweep - 1] == 0;
+    batch = 4;
+  }
+  X.sweeps_total += static_cast<uint64_t>(sweep);
+  X.frames += 1;
+  // the last sweep changed nothing: reach[sweep & 1] == reach[(sweep - 1) & 1], and eloc / tcarry belong to it
+  const u32* reach = X.reach[sweep & 1];
+  hipLaunchKernelGGL(k_fast_obs_commit, gv, dim3(256), 0, s, V, reach, X.eloc, X.tcarry, X.table_obs, F.cnt, vcap);
+  hipLaunchKernelGGL(k_fast_finish, gr, dim3(256), 0, s, F.rays, reach, F.cnt);
+  // updates: the record pipeline of `simple` (records sorted by voxel, replayed in visiting order)
+  COX_TRY(stage_b1(c, s));
+  COX_TRY(stage_b2(c, s));
+  return COX_OK;
+}
+
 // enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
 static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
   cox_layer* Lh = I->layer;
@@ -1582,6 +1682,16 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   P.frame_id = ++Lh->frame_id;
   I->h_params[slot] = P;
 
+  if (I->method == COX_METHOD_FAST) {  // single stream, see fast_frame
+    COX_TRY(fast_frame(ctx, I->st[0]));
+    COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
+    COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], F.cnt, sizeof(Counters), hipMemcpyDeviceToHost, I->st[0]));
+    COX_HIP(hipEventRecord(F.done, I->st[0]));
+    F.used = true;
+    I->last_has_counts = true;
+    COX_HIP(hipGetLastError());
+    return COX_OK;
+  }
   // A1
   if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-4 is done with this frame set
   if (B.used && I->st[1] != I->st[0]) COX_HIP(hipStreamWaitEvent(I->st[0], B.done, 0));  // frame t-2's A2 is done with this bundle set
@@ -1623,7 +1733,7 @@ static void fold_counters(cox_integrator* I) {
   for (int s = 0; s < 64; ++s)
     for (int k = 0; k < 5; ++k) sh[k] += c.shard[s][k];
   I->last.n_valid = sh[kShValid];
-  I->last.n_rays = (I->method == COX_METHOD_MERGED) ? c.n_rays : sh[kShRays];
+  I->last.n_rays = (I->method == COX_METHOD_SIMPLE) ? sh[kShRays] : c.n_rays;
   I->last.n_updates = sh[kShUpdates];
   I->last.n_touched_voxels = sh[kShVoxels];
   I->last.n_touched_blocks = c.n_touched;
@@ -1663,8 +1773,14 @@ extern "C" {
 int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out) {
   COX_ENTRY();
   if (!layer || !cfg || !out) return COX_ERR_INVALID_ARG;
-  if (method != COX_METHOD_SIMPLE && method != COX_METHOD_MERGED) return (method == COX_METHOD_FAST) ? COX_ERR_UNSUPPORTED : COX_ERR_INVALID_ARG;
+  if (method != COX_METHOD_SIMPLE && method != COX_METHOD_MERGED && method != COX_METHOD_FAST) return COX_ERR_INVALID_ARG;
   if (cfg->integration_order_mode != 0) return COX_ERR_UNSUPPORTED;
+  if (method == COX_METHOD_FAST) {
+    // reproduced: the reference at integrator_threads = 1 (with more threads its two lossy sets race and the result is
+    // not reproducible even by itself).  Not reproduced: a wall-clock budget, and the oracle-only exact-set variant.
+    if (cfg->max_integration_time_s < 3.0e38f || cfg->fast_exact_sets != 0) return COX_ERR_UNSUPPORTED;
+    if (cfg->clear_checks_every_n_frames < 1 || cfg->max_consecutive_ray_collisions < 0 || !(cfg->start_voxel_subsampling_factor > 0.0f)) return COX_ERR_INVALID_ARG;
+  }
   if (!(cfg->default_truncation_distance > 0.0f) || !(cfg->max_weight > 0.0f) || !(cfg->max_ray_length_m > 0.0f)) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(layer->device));
   cox_integrator* I = new (std::nothrow) cox_integrator();
@@ -1681,8 +1797,12 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   // The hardware runs at most two of these kernels side by side (measured: profiles/), so two
   // streams (ray generation | layer update) give all the overlap there is; COX_STREAMS=4 puts every stage on its own.
   I->n_streams = (std::getenv("COX_STREAMS") && std::atoi(std::getenv("COX_STREAMS")) == 4) ? 4 : 2;
+  if (method == COX_METHOD_FAST) {
+    I->n_streams = 1;
+    I->use_graphs = false;
+  }
   for (int k = 0; k < 4; ++k) {
-    if (I->n_streams == 2 && (k & 1)) {
+    if ((I->n_streams == 2 && (k & 1)) || (I->n_streams == 1 && k > 0)) {
       I->st[k] = I->st[k - 1];
     } else if (st == COX_OK && hipStreamCreateWithFlags(&I->st[k], hipStreamNonBlocking) != hipSuccess) {
       st = COX_ERR_NO_DEVICE;
@@ -1715,6 +1835,16 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_params), sizeof(FrameParams) * kFrameSets, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK) st = dev_realloc(&I->d_depth_n, 1);
+  if (st == COX_OK && method == COX_METHOD_FAST) {
+    FastState& X = I->fast;
+    st = dev_realloc(&X.table_start, kFastSlots);
+    if (st == COX_OK) st = dev_realloc(&X.table_obs, kFastSlots);
+    if (st == COX_OK) st = dev_realloc(&X.d_changed, kFastMaxSweeps);
+    if (st == COX_OK && (hipMemset(X.table_start, 0, sizeof(u64) * kFastSlots) != hipSuccess || hipMemset(X.table_obs, 0, sizeof(u64) * kFastSlots) != hipSuccess))
+      st = COX_ERR_NO_DEVICE;
+    if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&X.h_changed), sizeof(u32) * kFastMaxSweeps, hipHostMallocDefault) != hipSuccess)
+      st = COX_ERR_OUT_OF_MEMORY;
+  }
   if (st == COX_OK) {
     memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
     memset(I->h_params, 0, sizeof(FrameParams) * kFrameSets);
@@ -1740,6 +1870,15 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     }
   std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums};
+  {
+    FastState& X = I->fast;
+    for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
+                    static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.vray), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
+                    static_cast<void*>(X.tmax), static_cast<void*>(X.tcarry), static_cast<void*>(X.reach[0]), static_cast<void*>(X.reach[1]),
+                    static_cast<void*>(X.d_changed)})
+      ptrs.push_back(q);
+    if (X.h_changed) (void)hipHostFree(X.h_changed);
+  }
   std::vector<hipEvent_t> events = {I->ev_a1, I->ev_a2, I->ev_b1};
   for (FrameSet& F : I->fs) {
     const RayArrays& R = F.rays;

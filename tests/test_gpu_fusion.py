@@ -155,13 +155,78 @@ def test_pool_exhaustion_is_reported(hip):
     assert e.value.status == -4
 
 
-def test_fast_method_and_sorted_order_are_refused_loudly(hip):
+def test_unsupported_configurations_are_refused_loudly(hip):
     layer = Layer(hip, 0.05, capacity_blocks=64)
-    with pytest.raises(CoxError) as e:
-        Integrator(hip, layer, hip.default_config(), "fast")
+    with pytest.raises(CoxError) as e:   # a wall-clock budget cannot be reproduced
+        Integrator(hip, layer, hip.default_config(max_integration_time_s=0.01), "fast")
+    assert e.value.status == -6
+    with pytest.raises(CoxError) as e:   # the exact-set variant exists in the oracle only
+        Integrator(hip, layer, hip.default_config(fast_exact_sets=1), "fast")
     assert e.value.status == -6
     with pytest.raises(CoxError):
         Integrator(hip, layer, hip.default_config(integration_order_mode=1), "merged")
+
+
+FAST1 = dict(integrator_threads=1)  # the reference's fast integrator is only reproducible single-threaded
+
+
+@pytest.mark.parametrize("voxel", [0.10, 0.05])
+def test_fast_subsampled_frames_parity(hip, oracle, voxel):
+    """`method: fast` (what coxgraph's tsdf_server_*.yaml configure): start-voxel dedup and early termination through
+    the two lossy 2^20-slot sets, reproduced bit for bit."""
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="fast", voxel=voxel, frames=[0, 1, 2, 40, 41], subsample=5, capacity_blocks=4096, cfg_overrides=FAST1)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(voxel, rep, sa[-1])
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+    assert sa[0]["n_rays"] < sa[0]["n_valid"]            # the start set skipped points
+    assert sa[0]["n_updates"] < 40 * sa[0]["n_rays"]     # and rays stopped early
+
+
+def test_fast_full_frames_5cm_parity(hip, oracle):
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="fast", voxel=0.05, frames=[0, 1, 2, 3], capacity_blocks=8192, cfg_overrides=FAST1)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(rep, sa)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+@pytest.mark.parametrize("overrides", [
+    dict(clear_checks_every_n_frames=3),                 # the sets survive from frame to frame
+    dict(max_consecutive_ray_collisions=0),
+    dict(max_consecutive_ray_collisions=6),
+    dict(start_voxel_subsampling_factor=1.0),
+    dict(start_voxel_subsampling_factor=4.0, voxel_carving_enabled=0),
+    dict(use_const_weight=0, use_weight_dropoff=0, allow_clear=0),
+])
+def test_fast_config_variants(hip, oracle, overrides):
+    ov = dict(FAST1)
+    ov.update(overrides)
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="fast", voxel=0.05, frames=[0, 1, 2, 3, 4], subsample=3, capacity_blocks=8192, cfg_overrides=ov)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(overrides, rep, sa[-1])
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+def test_fast_known_answers(hip, oracle):
+    """two identical points -> the second is skipped; a slightly offset ray stops after
+    max_consecutive_ray_collisions + 1 already-seen voxels."""
+    cfg_kw = dict(default_truncation_distance=0.3, use_const_weight=1, min_ray_length_m=0.1, max_ray_length_m=5.0, integrator_threads=1)
+    pts = np.array([[1.05, 0.05, 0.05], [1.05, 0.05, 0.05], [1.05, 0.06, 0.05]], np.float32)
+    T = IDENT.copy()
+    T[4:] = [0.05, 0.05, 0.05]
+    res = []
+    for eng in (hip, oracle):
+        layer = Layer(eng, 0.1, capacity_blocks=64)
+        integ = Integrator(eng, layer, eng.default_config(**cfg_kw), "fast")
+        integ.integrate_points(T, pts - T[4:], None)
+        res.append((layer, integ.last_stats()))
+    (la, sa), (lb, sb) = res
+    assert {k: sa[k] for k in ("n_valid", "n_rays", "n_updates")} == {k: sb[k] for k in ("n_valid", "n_rays", "n_updates")}
+    assert sa["n_valid"] == 3 and sa["n_rays"] < 3      # the repeated point does not start a second ray
+    rep = compare_layers(la, lb)
+    assert rep["bitexact_d"] and rep["bitexact_w"]
 
 
 def test_layer_wire_roundtrip_merge_clear(hip, oracle):
