@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)  # the 300-frame 30 Hz stream of SURVEY.md section 8d
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--method", default="merged", choices=["merged", "simple"])
+    ap.add_argument("--method", default="merged", choices=["merged", "simple", "fast"])
+    ap.add_argument("--fast-frames", type=int, default=100, help="frames of the same stream also run through method 'fast' (0 = skip)")
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the CPU baseline sample (0 = skip); ~10 s of CPU work at the default")
     ap.add_argument("--reg-iters", type=int, default=50)
@@ -218,6 +219,27 @@ def main():
                "two_stage_solve_ms": solve_ms, "solve_evaluations": second["evaluations"],
                "solved_pose_error": [float(x) for x in pg.getPoseMap()[1]]}
 
+    # ---- the reference's configured method (`method: "fast"`, tsdf_server_euroc.yaml:6) on the same stream, for context ----
+    other = None
+    if rank == 0 and world == 1 and args.method != "fast" and args.fast_frames > 0:
+        nf = min(args.fast_frames, n_frames)
+        layer3 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+        integ3 = Integrator(eng, layer3, cfg, "fast")
+        for i in range(min(5, nf)):
+            T, xyz, rgba, n = dev_frames[i]
+            integ3.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+        integ3.sync()
+        layer3.clear()
+        t3 = time.perf_counter()
+        for i in range(nf):
+            T, xyz, rgba, n = dev_frames[i]
+            integ3.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+        integ3.sync()
+        dt3 = time.perf_counter() - t3
+        other = {"fast": {"value": nf / dt3, "unit": "frames/s", "frames": nf,
+                          "note": "FastTsdfIntegrator semantics at integrator_threads=1, bit-exact vs the CPU oracle (DESIGN.md section 5c)"}}
+        del integ3, layer3
+
     # ---- CPU baseline on rank 0, N = 1 only ---------------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
@@ -238,7 +260,7 @@ def main():
                                    f"{args.method} integrator semantics (bit-exact vs CPU oracle), points resident in HBM",
                        "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
             "frame_stats_mean": {k: v / max(args.steps, 1) for k, v in stats_sum.items()},
-            "roofline": roofline, "cpu_baseline": cpu, "registration": reg,
+            "roofline": roofline, "cpu_baseline": cpu, "registration": reg, "other_methods": other,
         }
         print(json.dumps(line))
     if world > 1:

@@ -151,10 +151,20 @@ __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restri
 }
 // visits of the frame (0 when the frame was dropped for overflowing the visit buffers)
 __device__ __forceinline__ u32 fast_num_visits(const Counters* cnt, u32 vcap) { return cnt->n_records > vcap ? 0u : cnt->n_records; }
-// position of every visit in the slot-sorted order
-__global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ vval_sorted, u32* __restrict__ pos_of, const Counters* cnt, u32 vcap) {
+// the visits in slot-sorted order: where each visit went (pos_of), and per sorted position its ray, its step on that
+// ray and its hash (so the sweeps read coalesced arrays instead of chasing visit -> ray -> offset)
+__global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ vval_sorted, const u32* __restrict__ vray, const u64* __restrict__ vhash,
+                                                      const u32* __restrict__ voff, u32* __restrict__ pos_of, u32* __restrict__ sray, u32* __restrict__ sstep,
+                                                      u64* __restrict__ shash, const Counters* cnt, u32 vcap) {
   const u32 n = fast_num_visits(cnt, vcap);
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pos_of[vval_sorted[i]] = i;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 v = vval_sorted[i];
+    const u32 r = vray[v];
+    pos_of[v] = i;
+    sray[i] = r;
+    sstep[i] = v - voff[r];
+    shash[i] = vhash[v];
+  }
 }
 
 template <int NW>
@@ -184,20 +194,16 @@ __device__ __forceinline__ u32 block_exclusive_max(u32 v, u32* total, u32* lds /
 }
 
 struct FastVisits {
-  const u32* vkey;   // slot of the visit at sorted position i
-  const u32* vval;   // visit index (ray-major) at sorted position i
-  const u32* vray;   // ray of visit v
-  const u64* vhash;  // hash of visit v
-  const u32* voff;   // first visit of ray r
-  const u32* pos_of;
+  const u32* skey;    // slot of the visit at sorted position i
+  const u32* sray;    // its ray
+  const u32* sstep;   // its step on that ray
+  const u64* shash;   // its hash
+  const u32* voff;    // first visit of ray r (ray-major numbering)
+  const u32* pos_of;  // sorted position of visit v
 };
 // is the visit at sorted position i performed under the current guess?  (steps 0 .. reach, the last one being the
 // operation that made the ray stop; a ray that never stops has reach == its whole walk)
-__device__ __forceinline__ bool fast_active(const FastVisits& V, const u32* __restrict__ reach, u32 i) {
-  const u32 v = V.vval[i];
-  const u32 r = V.vray[v];
-  return v - V.voff[r] <= reach[r];
-}
+__device__ __forceinline__ bool fast_active(const FastVisits& V, const u32* __restrict__ reach, u32 i) { return V.sstep[i] <= reach[V.sray[i]]; }
 // sweep, part 1: eloc[i] = 1 + the last performed position before i inside i's tile (0 = none), tmax[tile] = same over the tile
 __global__ void __launch_bounds__(256) k_fast_scan_tiles(FastVisits V, const u32* __restrict__ reach, u32* __restrict__ eloc, u32* __restrict__ tmax,
                                                          const Counters* cnt, u32 vcap) {
@@ -238,45 +244,57 @@ __global__ void __launch_bounds__(1024) k_fast_scan_carry(const u32* __restrict_
     carry = max(carry, total);
   }
 }
-// was the slot of the visit at position i last written with the same hash?
+// was the slot of the visit at sorted position i last written with the same hash?
 __device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tcarry,
-                                               const u64* __restrict__ table_obs, u32 i, u64 h) {
+                                               const u64* __restrict__ table_obs, u32 i) {
   const u32 e = max(eloc[i], tcarry[i / kFastTile]);
-  const u32 key = V.vkey[i];
-  const u64 prev = (e > 0 && V.vkey[e - 1] == key) ? V.vhash[V.vval[e - 1]] : table_obs[key];
-  return prev == h;
+  const u32 key = V.skey[i];
+  const u64 prev = (e > 0 && V.skey[e - 1] == key) ? V.shash[e - 1] : table_obs[key];
+  return prev == V.shash[i];
 }
-// sweep, part 3: thread = ray: walk, count consecutive collisions, stop like the reference does
-__global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, FastFrame FF, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
+// sweep, part 3: wave = ray.  64 steps of the walk are tested at once; the reference's "more than max_collisions
+// collisions in a row" is the first lane whose run of set bits (continued from the previous 64 steps) is long enough.
+__global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collisions, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
                                                     const u32* __restrict__ tcarry, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
                                                     u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt) {
   const u32 n_rays = cnt->n_rays;
+  const u32 lane = lane_id();
+  const u32 n_waves = (gridDim.x * blockDim.x) >> 6;
   bool any = false;
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
+  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_rays; r += n_waves) {
     const u32 ns = nfull[r], off = V.voff[r];
-    int col = 0;
-    u32 k = 0;
-    for (; k < ns; ++k) {
-      const u32 v = off + k;
-      if (fast_collision(V, eloc, tcarry, table_obs, V.pos_of[v], V.vhash[v])) ++col;
-      else col = 0;
-      if (col > FF.max_collisions) break;
+    u32 carry = 0, stop = ns;
+    for (u32 base = 0; base < ns; base += 64) {
+      const u32 k = base + lane;
+      const bool coll = (k < ns) && fast_collision(V, eloc, tcarry, table_obs, V.pos_of[off + k]);
+      const u64 m = __ballot(coll);
+      // length of the run of collisions that ends at this lane
+      const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+      const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
+      const u64 hit = __ballot(coll && run > static_cast<u32>(max_collisions));
+      if (hit) {
+        stop = base + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
+        break;
+      }
+      carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), 63));
     }
-    reach_out[r] = k;
-    any |= (k != reach_in[r]);
+    if (lane == 0) {
+      reach_out[r] = stop;
+      any |= (stop != reach_in[r]);
+    }
   }
-  if (__ballot(any) && lane_id() == 0) atomicOr(changed, 1u);
+  if (any) atomicOr(changed, 1u);
 }
 // after the last sweep: the table keeps the hash of the last performed operation on each slot
 __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32* __restrict__ reach, const u32* __restrict__ eloc, const u32* __restrict__ tcarry,
                                                          u64* __restrict__ table_obs, const Counters* cnt, u32 vcap) {
   const u32 n = fast_num_visits(cnt, vcap);
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 key = V.vkey[i];
-    if (i + 1 < n && V.vkey[i + 1] == key) continue;  // not the end of the slot's run
+    const u32 key = V.skey[i];
+    if (i + 1 < n && V.skey[i + 1] == key) continue;  // not the end of the slot's run
     u32 e = max(eloc[i], tcarry[i / kFastTile]);
     if (fast_active(V, reach, i)) e = i + 1;
-    if (e > 0 && V.vkey[e - 1] == key) table_obs[key] = V.vhash[V.vval[e - 1]];
+    if (e > 0 && V.skey[e - 1] == key) table_obs[key] = V.shash[e - 1];
   }
 }
 // hand the rays over to the record pipeline: a ray emits its first reach[r] voxels

@@ -1224,7 +1224,8 @@ struct RecordSet {  // lives B1 .. B2
 constexpr int kFastMaxSweeps = 512;
 struct FastState {
   u64 *fhash = nullptr, *vhash = nullptr, *table_start = nullptr, *table_obs = nullptr;
-  u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *tcarry = nullptr;
+  u64* shash = nullptr;
+  u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *tcarry = nullptr, *sray = nullptr, *sstep = nullptr;
   u32* reach[2] = {nullptr, nullptr};
   u32* d_changed = nullptr;  // [kFastMaxSweeps]
   u32* h_changed = nullptr;  // pinned mirror
@@ -1376,6 +1377,9 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&X.vray, rcap));
     COX_TRY(dev_realloc(&X.pos_of, rcap));
     COX_TRY(dev_realloc(&X.eloc, rcap));
+    COX_TRY(dev_realloc(&X.sray, rcap));
+    COX_TRY(dev_realloc(&X.sstep, rcap));
+    COX_TRY(dev_realloc(&X.shash, rcap));
     COX_TRY(dev_realloc(&X.tmax, rcap / kFastTile + 2));
     COX_TRY(dev_realloc(&X.tcarry, rcap / kFastTile + 2));
   }
@@ -1615,7 +1619,7 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   }
   const FastFrame FF{X.off_start, X.off_obs, I->cfg.max_consecutive_ray_collisions};
   const u32 n = I->pcap, vcap = I->rcap;
-  const dim3 gp = grid_for(n, 256, 4096), gv(2048), gr = grid_for(n, 256, 1024);
+  const dim3 gp = grid_for(n, 256, 4096), gv(2048), gr = grid_for(n, 256, 1024), gw(4096);  // gw: one wave per ray, grid-stride
   COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
   COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
   COX_HIP(hipMemsetAsync(X.d_changed, 0, sizeof(u32) * kFastMaxSweeps, s));
@@ -1631,24 +1635,30 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   hipLaunchKernelGGL(k_fast_visits, gr, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
   const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21), kFastSlotBits,
                                       false, 2, I->sort_rec, nullptr, s);
-  hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.pos_of, F.cnt, vcap);
-  const FastVisits V{S.rec_key[vp], S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of};
-  // Jacobi sweeps until one changes nothing
-  int sweep = 0, batch = 14;
+  hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
+  const FastVisits V{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
+  // Jacobi sweeps until one changes nothing.  (Capturing a batch into a HIP graph was measured: no gain, the sweeps are
+  // bound by their own dependent loads, not by launches.)
+  constexpr int kFirstBatch = 14;
+  auto enqueue = [&](int first, int count) -> int {
+    for (int k = first; k < first + count; ++k) {
+      hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
+      hipLaunchKernelGGL(k_fast_scan_carry, dim3(1), dim3(1024), 0, s, X.tmax, X.tcarry, F.cnt, vcap);
+      hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, F.rays.nsteps, X.eloc, X.tcarry, X.table_obs,
+                         X.reach[k & 1], X.reach[(k + 1) & 1], X.d_changed + k, F.cnt);
+    }
+    COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
+    return COX_OK;
+  };
+  int sweep = 0;
   bool converged = false;
   while (!converged) {
+    const int batch = (sweep == 0) ? kFirstBatch : 4;
     if (sweep + batch > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
-    const int first = sweep;
-    for (int k = 0; k < batch; ++k, ++sweep) {
-      hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[sweep & 1], X.eloc, X.tmax, F.cnt, vcap);
-      hipLaunchKernelGGL(k_fast_scan_carry, dim3(1), dim3(1024), 0, s, X.tmax, X.tcarry, F.cnt, vcap);
-      hipLaunchKernelGGL(k_fast_sweep, gr, dim3(256), 0, s, V, FF, F.rays.nsteps, X.eloc, X.tcarry, X.table_obs, X.reach[sweep & 1], X.reach[(sweep + 1) & 1],
-                         X.d_changed + sweep, F.cnt);
-    }
-    COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * batch, hipMemcpyDeviceToHost, s));
+    COX_TRY(enqueue(sweep, batch));
+    sweep += batch;
     COX_HIP(hipStreamSynchronize(s));
     converged = X.h_changed[sweep - 1] == 0;
-    batch = 4;
   }
   X.sweeps_total += static_cast<uint64_t>(sweep);
   X.frames += 1;
@@ -1873,7 +1883,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   {
     FastState& X = I->fast;
     for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
-                    static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.vray), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
+                    static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.vray), static_cast<void*>(X.sray), static_cast<void*>(X.sstep), static_cast<void*>(X.shash), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
                     static_cast<void*>(X.tmax), static_cast<void*>(X.tcarry), static_cast<void*>(X.reach[0]), static_cast<void*>(X.reach[1]),
                     static_cast<void*>(X.d_changed)})
       ptrs.push_back(q);
