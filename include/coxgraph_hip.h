@@ -49,7 +49,7 @@ typedef struct cox_integrator cox_integrator_t; /* voxblox::TsdfIntegratorBase *
 typedef struct cox_regpoints cox_regpoints_t;   /* voxgraph registration point set of a submap */
 typedef struct cox_reg cox_reg_t;               /* voxgraph::RegistrationCostFunction */
 
-/* integrator factory key: method in {"simple","merged","fast"}
+/* integrator factory key: method in {"simple","merged","fast"}; "fast" reproduces the reference at integrator_threads = 1
  * (coxgraph/config/tsdf_server_euroc.yaml:6, tsdf_server_default.yaml:6,
  *  coxgraph_sim/launch/experiments/mav_3dplanning_2d3dhouse_two.launch:10) */
 typedef enum cox_method { COX_METHOD_SIMPLE = 0, COX_METHOD_MERGED = 1, COX_METHOD_FAST = 2 } cox_method;
@@ -75,7 +75,7 @@ typedef struct cox_tsdf_config {
   float start_voxel_subsampling_factor; /* fast */
   int32_t max_consecutive_ray_collisions; /* fast */
   int32_t clear_checks_every_n_frames;    /* fast */
-  float max_integration_time_s;           /* fast; CPU oracle only */
+  float max_integration_time_s;           /* fast; a finite budget is refused by the HIP engine (wall-clock dependent) */
   int32_t merged_bundle_order;            /* CPU oracle only: 0 canonical, 1 libstdc++ map order */
   int32_t fast_exact_sets;                /* CPU oracle only: 0 ApproxHashSet, 1 exact sets */
 } cox_tsdf_config;
