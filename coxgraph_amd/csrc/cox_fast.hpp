@@ -119,36 +119,62 @@ __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict
 }
 
 // ---- observed set -------------------------------------------------------------------------------------------------
-// thread = ray: every voxel the ray would visit if nothing stopped it, in walking order
+// wave = ray: every voxel the ray would visit if nothing stopped it, in walking order (parallel DDA of the merged
+// integrator's bundles, wave_ray_path; sequential on lane 0 for the rays that one does not cover)
 __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ vhash, u32* __restrict__ vkey,
                                                      u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ reach, u32 vcap, Counters* cnt) {
   const FrameParams P = *Pp;
-  const u32 n_rays = cnt->n_rays;
-  const bool overflow = cnt->n_records > vcap;  // cannot happen unless the worst-case bound itself exceeds the 2^31 limit
+  __shared__ float lds_t[4][3 * kAxisCap];
+  __shared__ u32 lds_path[4][3 * kAxisCap];
+  const u32 n_rays = uniform_u32(cnt->n_rays);
+  const bool overflow = uniform_u32(cnt->n_records) > vcap;  // cannot happen unless the worst-case bound itself exceeds the 2^31 limit
   if (overflow && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, kErrRecords);
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x >> 6;
+  float* tl = lds_t[wave];
+  u32* path = lds_path[wave];
+  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_rays; r += waves_total) {
     if (overflow) {  // the frame is dropped as a whole
-      R.nsteps[r] = 0;
-      reach[r] = 0;
+      if (lane == 0) {
+        R.nsteps[r] = 0;
+        reach[r] = 0;
+      }
       continue;
     }
-    const u32 ns = R.nsteps[r];
-    reach[r] = ns;
+    const u32 ns = uniform_u32(R.nsteps[r]);
+    if (lane == 0) reach[r] = ns;
     if (ns == 0) continue;
-    const u32 off = R.rec_off[r];
-    const F3 pg{R.px[r], R.py[r], R.pz[r]};
+    const u32 off = uniform_u32(R.rec_off[r]);
+    const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
     Dda d;
-    dda_setup(d, P, pg, (R.flags[r] & 2u) != 0);
-    for (u32 s = 0; s < ns; ++s) {
-      const u64 h = long_index_hash(d.c[0], d.c[1], d.c[2]) + FF.off_obs;
-      dda_step(d);
-      vhash[off + s] = h;
-      vkey[off + s] = static_cast<u32>(h) & kFastSlotMask;
-      vval[off + s] = off + s;
-      vray[off + s] = r;
+    dda_setup(d, P, pg, (uniform_u32(R.flags[r]) & 2u) != 0);
+    if (wave_ray_path(d, ns, tl, path, lane)) {
+      for (u32 s = lane; s < ns; s += 64) {
+        const u32 p = path[s];
+        const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];
+        const int y = d.c[1] + static_cast<int>((p >> 10) & 1023u) * d.sgn[1];
+        const int z = d.c[2] + static_cast<int>(p >> 20) * d.sgn[2];
+        const u64 h = long_index_hash(x, y, z) + FF.off_obs;
+        vhash[off + s] = h;
+        vkey[off + s] = static_cast<u32>(h) & kFastSlotMask;
+        vval[off + s] = off + s;
+        vray[off + s] = r;
+      }
+      wave_lds_handover();  // the next ray of this wave reuses the LDS scratch
+    } else if (lane == 0) {
+      for (u32 s = 0; s < ns; ++s) {
+        const u64 h = long_index_hash(d.c[0], d.c[1], d.c[2]) + FF.off_obs;
+        dda_step(d);
+        vhash[off + s] = h;
+        vkey[off + s] = static_cast<u32>(h) & kFastSlotMask;
+        vval[off + s] = off + s;
+        vray[off + s] = r;
+      }
     }
   }
 }
+
 // visits of the frame (0 when the frame was dropped for overflowing the visit buffers)
 __device__ __forceinline__ u32 fast_num_visits(const Counters* cnt, u32 vcap) { return cnt->n_records > vcap ? 0u : cnt->n_records; }
 // the visits in slot-sorted order: where each visit went (pos_of), and per sorted position its ray, its step on that
@@ -229,33 +255,33 @@ __global__ void __launch_bounds__(256) k_fast_scan_tiles(FastVisits V, const u32
     if (threadIdx.x == 0) tmax[tile] = total;
   }
 }
-// sweep, part 2 (one workgroup): tcarry[tile] = 1 + last performed position before the tile
-__global__ void __launch_bounds__(1024) k_fast_scan_carry(const u32* __restrict__ tmax, u32* __restrict__ tcarry, const Counters* cnt, u32 vcap) {
-  __shared__ u32 lds[16];
-  const u32 n = fast_num_visits(cnt, vcap);
-  const u32 n_tiles = (n + kFastTile - 1) / kFastTile;
-  u32 carry = 0;
-  for (u32 base = 0; base < n_tiles; base += 1024) {
-    const u32 i = base + threadIdx.x;
-    const u32 v = (i < n_tiles) ? tmax[i] : 0u;
-    u32 total;
-    const u32 ex = block_exclusive_max<16>(v, &total, lds);
-    if (i < n_tiles) tcarry[i] = max(carry, ex);
-    carry = max(carry, total);
+// 1 + sorted position of the last performed visit of slot `key` before position i (0 = none this frame).
+// eloc covers i's own tile; a slot's visits are contiguous, so earlier tiles only matter while the run reaches back
+// into them, and there the candidate is that tile's last performed visit (tmax): either it belongs to the run, or --
+// keys being sorted -- no performed visit of the run lies in that tile and the run starts behind it.
+__device__ __forceinline__ u32 fast_prev_performed(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tmax, u32 i, u32 key) {
+  const u32 e = eloc[i];
+  if (e > 0) return V.skey[e - 1] == key ? e : 0u;
+  u32 t = i / kFastTile;
+  while (t > 0 && V.skey[t * kFastTile - 1] == key) {
+    --t;
+    const u32 m = tmax[t];
+    if (m > 0) return V.skey[m - 1] == key ? m : 0u;
   }
+  return 0u;
 }
 // was the slot of the visit at sorted position i last written with the same hash?
-__device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tcarry,
+__device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tmax,
                                                const u64* __restrict__ table_obs, u32 i) {
-  const u32 e = max(eloc[i], tcarry[i / kFastTile]);
   const u32 key = V.skey[i];
-  const u64 prev = (e > 0 && V.skey[e - 1] == key) ? V.shash[e - 1] : table_obs[key];
+  const u32 e = fast_prev_performed(V, eloc, tmax, i, key);
+  const u64 prev = e ? V.shash[e - 1] : table_obs[key];
   return prev == V.shash[i];
 }
-// sweep, part 3: wave = ray.  64 steps of the walk are tested at once; the reference's "more than max_collisions
+// sweep, part 3: wave = ray.  Up to 256 steps of the walk are tested at once; the reference's "more than max_collisions
 // collisions in a row" is the first lane whose run of set bits (continued from the previous 64 steps) is long enough.
 __global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collisions, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
-                                                    const u32* __restrict__ tcarry, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
+                                                    const u32* __restrict__ tmax, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
                                                     u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt) {
   const u32 n_rays = cnt->n_rays;
   const u32 lane = lane_id();
@@ -264,19 +290,32 @@ __global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collis
   for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_rays; r += n_waves) {
     const u32 ns = nfull[r], off = V.voff[r];
     u32 carry = 0, stop = ns;
-    for (u32 base = 0; base < ns; base += 64) {
-      const u32 k = base + lane;
-      const bool coll = (k < ns) && fast_collision(V, eloc, tcarry, table_obs, V.pos_of[off + k]);
-      const u64 m = __ballot(coll);
-      // length of the run of collisions that ends at this lane
-      const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-      const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
-      const u64 hit = __ballot(coll && run > static_cast<u32>(max_collisions));
-      if (hit) {
-        stop = base + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
-        break;
+    // Most rays stop within their first few steps and every tested step costs half a dozen gathers, so the walk is
+    // tested in growing segments: 16 steps, the rest of the first 64, then 256 at a time (four independent gathers
+    // per lane in flight) for the few rays that are still going.
+    u32 base = 0, seg = 16;
+    while (base < ns && stop == ns) {
+      const u32 len = uniform_u32(min(seg, ns - base));
+      bool coll[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 q = 64u * j + lane;
+        coll[j] = (q < len) && fast_collision(V, eloc, tmax, table_obs, V.pos_of[off + base + q]);
       }
-      carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), 63));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (stop != ns || 64u * j >= len) break;
+        const u32 sub = uniform_u32(min(64u, len - 64u * j));  // lanes of this group that hold a step
+        const u64 m = __ballot(coll[j]);
+        // length of the run of collisions that ends at this lane
+        const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
+        const u64 hit = __ballot(coll[j] && run > static_cast<u32>(max_collisions));
+        if (hit) stop = base + 64u * j + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
+        carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), static_cast<int>(sub - 1u)));
+      }
+      base += len;
+      seg = (base < 64u) ? 64u - base : 256u;
     }
     if (lane == 0) {
       reach_out[r] = stop;
@@ -286,15 +325,14 @@ __global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collis
   if (any) atomicOr(changed, 1u);
 }
 // after the last sweep: the table keeps the hash of the last performed operation on each slot
-__global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32* __restrict__ reach, const u32* __restrict__ eloc, const u32* __restrict__ tcarry,
+__global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32* __restrict__ reach, const u32* __restrict__ eloc, const u32* __restrict__ tmax,
                                                          u64* __restrict__ table_obs, const Counters* cnt, u32 vcap) {
   const u32 n = fast_num_visits(cnt, vcap);
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u32 key = V.skey[i];
     if (i + 1 < n && V.skey[i + 1] == key) continue;  // not the end of the slot's run
-    u32 e = max(eloc[i], tcarry[i / kFastTile]);
-    if (fast_active(V, reach, i)) e = i + 1;
-    if (e > 0 && V.skey[e - 1] == key) table_obs[key] = V.shash[e - 1];
+    const u32 e = fast_active(V, reach, i) ? i + 1 : fast_prev_performed(V, eloc, tmax, i, key);
+    if (e) table_obs[key] = V.shash[e - 1];
   }
 }
 // hand the rays over to the record pipeline: a ray emits its first reach[r] voxels

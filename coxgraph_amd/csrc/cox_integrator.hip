@@ -550,8 +550,6 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
   }
 }
 
-#include "cox_fast.hpp"
-
 // ---- wave-per-ray traversal (few, long rays: the merged integrator's bundles) -----------------------------
 // A DDA is a dependent chain, so lane-per-ray leaves the chip empty when a frame has only a few thousand rays.
 // Here one wave walks one ray in parallel and reproduces the sequential argmin walk bit for bit:
@@ -816,6 +814,8 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
     }
   }
 }
+
+#include "cox_fast.hpp"
 
 // ---- apply: per voxel, the running weighted-mean / clamp update in canonical ray order -----------------
 // After the stable sort the records of one voxel are contiguous ("segment") and in ray order.
@@ -1225,7 +1225,7 @@ constexpr int kFastMaxSweeps = 512;
 struct FastState {
   u64 *fhash = nullptr, *vhash = nullptr, *table_start = nullptr, *table_obs = nullptr;
   u64* shash = nullptr;
-  u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *tcarry = nullptr, *sray = nullptr, *sstep = nullptr;
+  u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *sray = nullptr, *sstep = nullptr;
   u32* reach[2] = {nullptr, nullptr};
   u32* d_changed = nullptr;  // [kFastMaxSweeps]
   u32* h_changed = nullptr;  // pinned mirror
@@ -1381,7 +1381,6 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&X.sstep, rcap));
     COX_TRY(dev_realloc(&X.shash, rcap));
     COX_TRY(dev_realloc(&X.tmax, rcap / kFastTile + 2));
-    COX_TRY(dev_realloc(&X.tcarry, rcap / kFastTile + 2));
   }
   const u32 need_scan = scan_num_blocks(cap) + 2;
   if (need_scan > I->scan_cap) {
@@ -1632,19 +1631,20 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, F.cnt);
   // candidate visits: every voxel of every ray's whole walk, sorted by slot of the observed set
   exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
-  hipLaunchKernelGGL(k_fast_visits, gr, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
+  hipLaunchKernelGGL(k_fast_visits, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
   const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21), kFastSlotBits,
                                       false, 2, I->sort_rec, nullptr, s);
   hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
   const FastVisits V{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
   // Jacobi sweeps until one changes nothing.  (Capturing a batch into a HIP graph was measured: no gain, the sweeps are
   // bound by their own dependent loads, not by launches.)
-  constexpr int kFirstBatch = 14;
+  // sweeps between two looks at the "changed" flags: measured on the benchmark stream (frames/s): 14+4: 1275, 8+2: 1503,
+  // 4+2: 1601, 2+1: 1564 -- most frames settle within a handful of sweeps, the first frames of a stream need 14-18
+  constexpr int kFirstBatch = 4, kNextBatch = 2;
   auto enqueue = [&](int first, int count) -> int {
     for (int k = first; k < first + count; ++k) {
       hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
-      hipLaunchKernelGGL(k_fast_scan_carry, dim3(1), dim3(1024), 0, s, X.tmax, X.tcarry, F.cnt, vcap);
-      hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, F.rays.nsteps, X.eloc, X.tcarry, X.table_obs,
+      hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, F.rays.nsteps, X.eloc, X.tmax, X.table_obs,
                          X.reach[k & 1], X.reach[(k + 1) & 1], X.d_changed + k, F.cnt);
     }
     COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
@@ -1653,7 +1653,7 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   int sweep = 0;
   bool converged = false;
   while (!converged) {
-    const int batch = (sweep == 0) ? kFirstBatch : 4;
+    const int batch = (sweep == 0) ? kFirstBatch : kNextBatch;
     if (sweep + batch > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
     COX_TRY(enqueue(sweep, batch));
     sweep += batch;
@@ -1662,9 +1662,9 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   }
   X.sweeps_total += static_cast<uint64_t>(sweep);
   X.frames += 1;
-  // the last sweep changed nothing: reach[sweep & 1] == reach[(sweep - 1) & 1], and eloc / tcarry belong to it
+  // the last sweep changed nothing: reach[sweep & 1] == reach[(sweep - 1) & 1], and eloc / tmax belong to it
   const u32* reach = X.reach[sweep & 1];
-  hipLaunchKernelGGL(k_fast_obs_commit, gv, dim3(256), 0, s, V, reach, X.eloc, X.tcarry, X.table_obs, F.cnt, vcap);
+  hipLaunchKernelGGL(k_fast_obs_commit, gv, dim3(256), 0, s, V, reach, X.eloc, X.tmax, X.table_obs, F.cnt, vcap);
   hipLaunchKernelGGL(k_fast_finish, gr, dim3(256), 0, s, F.rays, reach, F.cnt);
   // updates: the record pipeline of `simple` (records sorted by voxel, replayed in visiting order)
   COX_TRY(stage_b1(c, s));
@@ -1884,7 +1884,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     FastState& X = I->fast;
     for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
                     static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.vray), static_cast<void*>(X.sray), static_cast<void*>(X.sstep), static_cast<void*>(X.shash), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
-                    static_cast<void*>(X.tmax), static_cast<void*>(X.tcarry), static_cast<void*>(X.reach[0]), static_cast<void*>(X.reach[1]),
+                    static_cast<void*>(X.tmax), static_cast<void*>(X.reach[0]), static_cast<void*>(X.reach[1]),
                     static_cast<void*>(X.d_changed)})
       ptrs.push_back(q);
     if (X.h_changed) (void)hipHostFree(X.h_changed);
