@@ -47,8 +47,8 @@ def build(eng):
     g["ray_path_lengths"] = np.array([len(p) for p in paths], np.int64)
     g["ray_paths"] = np.concatenate(paths, axis=0)
     # 2. small integration: every 16th pixel of frames 0 and 7, 10 cm, merged and simple
-    for method in ("merged", "simple"):
-        cfg = eng.default_config(**synth.integrator_overrides(0.10))
+    for method in ("merged", "simple", "fast"):
+        cfg = eng.default_config(integrator_threads=1, **synth.integrator_overrides(0.10))  # fast: only the single-threaded result is defined
         layer = Layer(eng, 0.10, capacity_blocks=4096)
         integ = Integrator(eng, layer, cfg, method)
         stats = []
@@ -82,6 +82,25 @@ def build(eng):
     g["reg_pose_ref"], g["reg_pose_read"] = pr, pd
     g["reg_residuals"], g["reg_jac_ref"], g["reg_jac_read"] = r, jf, jr
     g["reg_H"], g["reg_b"], g["reg_cost_ncorr"] = H, b, np.array([cost, nc])
+    # 4. recover mode: mesh with history -> per-pose clouds -> layer (synthetic wall mesh, seed 11)
+    from coxgraph_amd.capi import MeshMsg, MeshConverter  # noqa: E402
+    m = synth.make_wall_mesh(seed=11, n_frames=8)
+    msg = MeshMsg(m["block_edge_length"], m["blocks"], m["trajectory"])
+    conv = MeshConverter(eng, 0.07)
+    conv.set_mesh(msg)
+    ok, rec, rgb = conv.convert()
+    clouds = conv.pose_clouds()
+    g["mesh_recovered_sha256"] = np.frombuffer(hashlib.sha256(rec.tobytes() + rgb.tobytes()).digest(), np.uint8)
+    g["mesh_cloud_sizes"] = np.array([len(c[1]) for c in clouds], np.int64)
+    g["mesh_clouds_sha256"] = np.frombuffer(hashlib.sha256(b"".join(c[1].tobytes() + c[2].tobytes() for c in clouds)).digest(), np.uint8)
+    g["mesh_cloud3_head"] = clouds[3][1][:16].copy()
+    cfg = eng.default_config(**synth.integrator_overrides(0.05))
+    layer = Layer(eng, 0.05, capacity_blocks=4096)
+    integ = Integrator(eng, layer, cfg, "merged")
+    n_rec, n_int = MeshConverter(eng, 0.07).process_mesh(integ, msg)
+    idx, vox = layer.download()
+    g["mesh_process_counts"] = np.array([n_rec, n_int, len(idx)], np.int64)
+    g["mesh_layer_sha256"] = np.frombuffer(hashlib.sha256(idx.tobytes() + vox.tobytes()).digest(), np.uint8)
     return g
 
 

@@ -15,7 +15,7 @@ G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 
 
 def _integrate(eng, method):
-    cfg = eng.default_config(**synth.integrator_overrides(0.10))
+    cfg = eng.default_config(integrator_threads=1, **synth.integrator_overrides(0.10))
     layer = Layer(eng, 0.10, capacity_blocks=4096)
     integ = Integrator(eng, layer, cfg, method)
     stats = []
@@ -66,7 +66,38 @@ def test_oracle_reproduces_golden_ray_paths(oracle):
         off += n
 
 
-@pytest.mark.parametrize("method", ["merged", "simple"])
+def _check_mesh(eng):
+    from coxgraph_amd.capi import MeshMsg, MeshConverter
+    m = synth.make_wall_mesh(seed=11, n_frames=8)
+    msg = MeshMsg(m["block_edge_length"], m["blocks"], m["trajectory"])
+    conv = MeshConverter(eng, 0.07)
+    conv.set_mesh(msg)
+    ok, rec, rgb = conv.convert()
+    clouds = conv.pose_clouds()
+    sha = lambda b: np.frombuffer(hashlib.sha256(b).digest(), np.uint8)
+    assert ok and np.array_equal(sha(rec.tobytes() + rgb.tobytes()), G["mesh_recovered_sha256"])
+    assert np.array_equal([len(c[1]) for c in clouds], G["mesh_cloud_sizes"])
+    assert np.array_equal(clouds[3][1][:16], G["mesh_cloud3_head"])
+    assert np.array_equal(sha(b"".join(c[1].tobytes() + c[2].tobytes() for c in clouds)), G["mesh_clouds_sha256"])
+    cfg = eng.default_config(**synth.integrator_overrides(0.05))
+    layer = Layer(eng, 0.05, capacity_blocks=4096)
+    integ = Integrator(eng, layer, cfg, "merged")
+    n_rec, n_int = MeshConverter(eng, 0.07).process_mesh(integ, msg)
+    idx, vox = layer.download()
+    assert np.array_equal([n_rec, n_int, len(idx)], G["mesh_process_counts"])
+    assert np.array_equal(sha(idx.tobytes() + vox.tobytes()), G["mesh_layer_sha256"])
+
+
+def test_oracle_reproduces_golden_mesh_recover(oracle):
+    _check_mesh(oracle)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_mesh_recover(hip):
+    _check_mesh(hip)
+
+
+@pytest.mark.parametrize("method", ["merged", "simple", "fast"])
 def test_oracle_reproduces_golden_layers(oracle, method):
     _check_integration(oracle, method)
 
@@ -77,7 +108,7 @@ def test_oracle_reproduces_golden_registration(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["merged", "simple"])
+@pytest.mark.parametrize("method", ["merged", "simple", "fast"])
 def test_hip_reproduces_golden_layers(hip, method):
     """Bit-identical voxel words (sha256 of the whole serialised layer) without the oracle in the loop."""
     _check_integration(hip, method)
