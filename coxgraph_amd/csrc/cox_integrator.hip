@@ -1289,8 +1289,11 @@ static int dev_realloc(T** p, size_t count) {
 
 static int alloc_sort_ws(SortWorkspace* ws, u64 capacity) {
   ws->tiles_cap = std::max<u32>(1, sort_num_tiles(capacity));
-  COX_TRY(dev_realloc(&ws->counts, static_cast<size_t>(ws->tiles_cap) * (1u << 11)));
-  if (!ws->totals) COX_TRY(dev_realloc(&ws->totals, static_cast<size_t>(kRsMaxPasses) * (1u << 11)));
+  COX_TRY(dev_realloc(&ws->counts, sort_counts_words(ws->tiles_cap)));
+  if (!ws->totals) {
+    COX_TRY(dev_realloc(&ws->totals, sort_totals_words()));
+    COX_HIP(hipMemset(ws->totals, 0, sizeof(u32) * sort_totals_words()));  // every sort leaves it zero again
+  }
   return COX_OK;
 }
 
@@ -1535,9 +1538,10 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
                        F.fh_keys, fh_mask);
   }
-  // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: up to 3 passes of 11 bits.
+  // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
+  // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
   // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
-  (void)radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true, 3,
+  (void)radix_sort_pairs<12>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true, 3,
                              I->sort_rec, S.sort_info, s);
   return COX_OK;
 }

@@ -518,9 +518,10 @@ int cox_meshconv_convert(cox_meshconv_t* C, uint64_t* n_recovered_points, int* c
     COX_TRY(dev_alloc(&C->d_cloud_rgba, n_points));
     if (n_pairs) {
       sortws.tiles_cap = std::max<u32>(1, sort_num_tiles(n_pairs));
-      COX_TRY(dev_alloc(&sortws.counts, static_cast<size_t>(sortws.tiles_cap) * (1u << 11)));
-      COX_TRY(dev_alloc(&sortws.totals, static_cast<size_t>(kRsMaxPasses) * (1u << 11)));
-      const int res = radix_sort_pairs<8>(pk[0], pt[0], pk[1], pt[1], nullptr, n_pairs, n_pairs, 8, false, 1, sortws, nullptr, s);
+      COX_TRY(dev_alloc(&sortws.counts, sort_counts_words(sortws.tiles_cap)));
+      COX_TRY(dev_alloc(&sortws.totals, sort_totals_words()));
+      COX_HIP(hipMemsetAsync(sortws.totals, 0, sizeof(u32) * sort_totals_words(), s));
+      const int res = radix_sort_pairs<11>(pk[0], pt[0], pk[1], pt[1], nullptr, n_pairs, n_pairs, 8, false, 1, sortws, nullptr, s);
       COX_TRY(dev_alloc(&psize, n_pairs));
       COX_TRY(dev_alloc(&out_off, n_pairs));
       COX_TRY(dev_alloc(&d_key_begin, 257));

@@ -140,14 +140,30 @@ struct SortInfo {
   u32 parity;  // 0: result in buffer 0, 1: result in buffer 1 (written by the kernels)
 };
 
+// Digit layout of one sort: the nbits key bits are split evenly over ceil(nbits / RB) passes (23 bits with RB = 12 ->
+// 12 + 12, 20 bits with RB = 11 -> 10 + 10), at least 6 bits per pass (the offsets kernel works in groups of 64 digits).
+// A last digit that reaches above nbits is harmless: keys are < 2^nbits or all ones.  Returns false when `pass` has
+// nothing to do.  Computed identically by the three kernels of a pass and by the host.
+template <int RB>
+__host__ __device__ __forceinline__ bool rs_pass_digits(u32 nbits, int pass, int* shift, u32* bits) {
+  if (nbits == 0) return false;
+  const u32 np = (nbits + RB - 1) / RB;
+  u32 w = (nbits + np - 1) / np;
+  if (w < 6) w = 6;
+  *shift = pass * static_cast<int>(w);
+  *bits = w;
+  return static_cast<u32>(*shift) < nbits;
+}
+
 template <int RB>
 __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ k0, const u32* __restrict__ k1, const u32* __restrict__ d_n, u32 n_max,
-                                                        int pass, const SortInfo* __restrict__ info, int host_bits, u32* __restrict__ counts /*[n_tiles][2^RB]*/,
-                                                        u32 tiles_cap, u32* __restrict__ totals /*[2^RB]*/) {
-  constexpr u32 kDigits = 1u << RB;
-  __shared__ u32 h[kDigits];
-  const int shift = pass * RB;
-  if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
+                                                        int pass, const SortInfo* __restrict__ info, int host_bits,
+                                                        u32* __restrict__ counts /*[n_tiles][2^bits]*/, u32 tiles_cap, u32* __restrict__ totals /*[2^bits]*/) {
+  __shared__ u32 h[1u << RB];  // RB = widest digit; this pass sorts on `bits` <= RB bits at `shift`
+  int shift;
+  u32 bits;
+  if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
+  const u32 kDigits = 1u << bits;
   const u32* keys = (pass & 1) ? k1 : k0;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 tile_elems = static_cast<u32>(kRsTile) << rs_tile_shift(n);
@@ -175,13 +191,15 @@ constexpr int kRsOffThreads = 1024;
 template <int RB>
 __global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restrict__ d_n, u32 n_max, int pass, SortInfo* __restrict__ info, int host_bits,
                                                               u32* __restrict__ counts, u32 tiles_cap, const u32* __restrict__ totals) {
-  constexpr u32 kDigits = 1u << RB;
+  int shift;
+  u32 bits;
+  if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
+  const u32 kDigits = 1u << bits;
+  if (blockIdx.x * 64u >= kDigits) return;  // the grid covers 2^RB digits
   constexpr u32 kWaves = kRsOffThreads / 64;
   __shared__ u32 lds[16];
   __shared__ u32 part[kWaves][64];
   __shared__ u32 group_base;
-  const int shift = pass * RB;
-  if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 tile_elems = static_cast<u32>(kRsTile) << rs_tile_shift(n);
   const u32 n_tiles = (n + tile_elems - 1) / tile_elems;
@@ -221,13 +239,15 @@ __global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restr
 
 // wave-wide "which lanes hold my digit" (RB ballots), restricted to lanes with valid == true
 template <int RB>
-__device__ __forceinline__ u64 match_digit(u32 digit, bool valid) {
+__device__ __forceinline__ u64 match_digit(u32 digit, bool valid, u32 bits) {
   u64 peers = __ballot(valid);
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
-    const bool bit = (digit >> b) & 1u;
-    const u64 m = __ballot(bit);
-    peers &= bit ? m : ~m;
+    if (static_cast<u32>(b) < bits) {  // wave-uniform
+      const bool bit = (digit >> b) & 1u;
+      const u64 m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
   }
   return peers;
 }
@@ -235,11 +255,15 @@ __device__ __forceinline__ u64 match_digit(u32 digit, bool valid) {
 template <int RB>
 __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0, u32* __restrict__ v0, u32* __restrict__ k1, u32* __restrict__ v1,
                                                            const u32* __restrict__ d_n, u32 n_max, int pass, const SortInfo* __restrict__ info, int host_bits,
-                                                           const u32* __restrict__ offsets, u32 tiles_cap) {
-  constexpr u32 kDigits = 1u << RB;
-  __shared__ u32 base[kRsWaves][kDigits];  // first per-wave digit counts, then per-wave running output positions
-  const int shift = pass * RB;
-  if (static_cast<u32>(shift) >= (host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits)) return;
+                                                           const u32* __restrict__ offsets, u32 tiles_cap, u32* __restrict__ totals) {
+  __shared__ u32 base[kRsWaves][1u << RB];  // first per-wave digit counts, then per-wave running output positions
+  int shift;
+  u32 bits;
+  if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
+  const u32 kDigits = 1u << bits;
+  // the digit totals of this pass were consumed by the offsets kernel: leave them zero for the next sort (no memset per sort)
+  if (blockIdx.x == 0)
+    for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) totals[d] = 0;
   const u32* keys_in = (pass & 1) ? k1 : k0;
   const u32* vals_in = (pass & 1) ? v1 : v0;
   u32* keys_out = (pass & 1) ? k0 : k1;
@@ -285,7 +309,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
         val = vals_in[i];
       }
       const u32 digit = (key >> shift) & (kDigits - 1);
-      const u64 peers = match_digit<RB>(digit, valid);
+      const u64 peers = match_digit<RB>(digit, valid, bits);
       const u64 lower = peers & ((1ull << lane) - 1ull);
       if (valid) {
         const u32 pos = my_base[digit] + static_cast<u32>(__popcll(lower));
@@ -300,32 +324,35 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
   }
 }
 
+constexpr u32 kRsMaxDigitBits = 12;
 struct SortWorkspace {
-  u32* counts = nullptr;   // [tiles_cap][2^11]
+  u32* counts = nullptr;   // [tiles_cap][2^kRsMaxDigitBits]
   u32 tiles_cap = 0;       // >= ceil(capacity / kRsTile)
-  u32* totals = nullptr;   // [kRsMaxPasses][2^11], zeroed by the sort
+  u32* totals = nullptr;   // [kRsMaxPasses][2^kRsMaxDigitBits]: zero when allocated, left zero by every sort
 };
 static inline u32 sort_num_tiles(u64 n) { return static_cast<u32>((n + kRsTile - 1) / kRsTile); }
+static inline size_t sort_counts_words(u32 tiles_cap) { return static_cast<size_t>(tiles_cap) << kRsMaxDigitBits; }
+static inline size_t sort_totals_words() { return static_cast<size_t>(kRsMaxPasses) << kRsMaxDigitBits; }
 
-// Sorts (k0,v0) by key bits [0, nbits).  Buffers ping-pong; the buffer that holds the result is
-// returned when nbits is known on the host (bits_on_device == false).  Otherwise nbits is read from
-// info->nbits (written by an earlier kernel of the frame), max_passes passes are enqueued (surplus
-// ones exit at once), the result buffer is reported in info->parity (device) and -1 is returned.
+// Sorts (k0,v0) by key bits [0, nbits) in ceil(nbits / RB) passes of equal width (rs_pass_digits).  Buffers ping-pong;
+// the buffer that holds the result is returned when nbits is known on the host (bits_on_device == false).  Otherwise
+// nbits is read from info->nbits (written by an earlier kernel of the frame), max_passes passes are enqueued (surplus
+// ones exit at once), the result buffer is reported in info->parity (device) and -1 is returned.  RB = 11 or 12.
 template <int RB>
 static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32* d_n, u32 n_max, u32 n_hint, int host_bits, bool bits_on_device,
                                    int max_passes, const SortWorkspace& ws, SortInfo* info, hipStream_t s) {
+  static_assert(RB >= 6 && RB <= static_cast<int>(kRsMaxDigitBits), "digit width");
   const u32 nt = sort_num_tiles(n_hint ? n_hint : 1);
   const u32 grid = nt < 1 ? 1 : (nt > 8192 ? 8192 : nt);
   int passes = max_passes;
   if (!bits_on_device) passes = (host_bits + RB - 1) / RB;
   if (passes > kRsMaxPasses) passes = kRsMaxPasses;
   const int hb = bits_on_device ? -1 : host_bits;
-  (void)hipMemsetAsync(ws.totals, 0, sizeof(u32) * kRsMaxPasses * (1u << 11), s);
   for (int p = 0; p < passes; ++p) {
-    u32* totals = ws.totals + static_cast<size_t>(p) * (1u << 11);
+    u32* totals = ws.totals + (static_cast<size_t>(p) << kRsMaxDigitBits);
     hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
     hipLaunchKernelGGL(k_rs_offsets<RB>, dim3((1u << RB) / 64u), dim3(kRsOffThreads), 0, s, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
-    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap);
+    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
   }
   return bits_on_device ? -1 : (passes & 1);
 }
