@@ -282,7 +282,7 @@ class Registration:
         pd = np.ascontiguousarray(pose_read, np.float64)
         assert pr.shape == (4,) and pd.shape == (4,)
         if sample_idx is None:
-            return pr, pd, None, self.ref.n
+            return pr, pd, None, (getattr(self, "stored_n", None) or self.ref.n)
         si = np.ascontiguousarray(sample_idx, np.uint32)
         return pr, pd, si, si.shape[0]
 
@@ -304,6 +304,27 @@ class Registration:
         cost, nc = C.c_double(), C.c_uint64()
         self.eng.check(self.eng.fn("reg_normal_eq")(self.h, _fp(pr), _fp(pd), _fp(si) if si is not None else None, C.c_uint64(n),
                                                     _fp(H), _fp(b), C.byref(cost), C.byref(nc)), "reg_normal_eq")
+        return H, b, float(cost.value), int(nc.value)
+
+    def set_samples(self, sample_idx):
+        """Keep the sample indices on the engine's side; later calls pass sample_idx=None and use them."""
+        if sample_idx is None:
+            self.eng.check(self.eng.fn("reg_set_samples")(self.h, None, C.c_uint64(0)), "reg_set_samples")
+            self.stored_n = None
+            return
+        si = np.ascontiguousarray(sample_idx, np.uint32)
+        self.eng.check(self.eng.fn("reg_set_samples")(self.h, _fp(si), C.c_uint64(si.shape[0])), "reg_set_samples")
+        self.stored_n = int(si.shape[0])
+
+    def normal_eq_begin(self, pose_ref, pose_read, sample_idx=None):
+        pr, pd, si, n = self._args(pose_ref, pose_read, sample_idx)
+        self.eng.check(self.eng.fn("reg_normal_eq_begin")(self.h, _fp(pr), _fp(pd), _fp(si) if si is not None else None, C.c_uint64(n)), "reg_normal_eq_begin")
+
+    def normal_eq_finish(self):
+        H = np.zeros((8, 8), np.float64)
+        b = np.zeros(8, np.float64)
+        cost, nc = C.c_double(), C.c_uint64()
+        self.eng.check(self.eng.fn("reg_normal_eq_finish")(self.h, _fp(H), _fp(b), C.byref(cost), C.byref(nc)), "reg_normal_eq_finish")
         return H, b, float(cost.value), int(nc.value)
 
     def kernel_time(self, reset=False):

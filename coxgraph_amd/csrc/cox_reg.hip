@@ -285,6 +285,11 @@ struct cox_reg {
   hipStream_t stream = nullptr;
   u32* d_idx = nullptr;
   u64 idx_cap = 0;
+  u32* d_stored = nullptr;  // cox_reg_set_samples: indices kept on the GPU, used when a call passes sample_idx == NULL
+  u64 stored_cap = 0, stored_samples = 0;
+  bool has_stored = false;
+  bool pending = false;    // a cox_reg_normal_eq_begin without its finish
+  u64 pending_n = 0;
   double *d_res = nullptr, *d_jf = nullptr, *d_jr = nullptr;
   u64 res_cap = 0, jf_cap = 0, jr_cap = 0;
   double* d_small = nullptr;  // block sums / partials / results
@@ -318,6 +323,11 @@ static ReadingView reading_view(const cox_layer* L) {
 
 static int stage_samples(cox_reg* G, const uint32_t* sample_idx, uint64_t n_res, const u32** d_idx_out) {
   *d_idx_out = nullptr;
+  if (!sample_idx && G->has_stored) {
+    if (n_res != G->stored_samples) return COX_ERR_INVALID_ARG;
+    *d_idx_out = G->d_stored;
+    return COX_OK;
+  }
   if (!sample_idx) return (n_res == G->ref->n) ? COX_OK : COX_ERR_INVALID_ARG;
   for (uint64_t i = 0; i < n_res; ++i)
     if (sample_idx[i] >= G->ref->n) return COX_ERR_INVALID_ARG;
@@ -390,7 +400,7 @@ void cox_reg_destroy(cox_reg_t* G) {
   if (!G) return;
   (void)hipSetDevice(G->reading->device);
   if (G->stream) (void)hipStreamSynchronize(G->stream);
-  void* ptrs[] = {G->d_idx, G->d_res, G->d_jf, G->d_jr, G->d_small};
+  void* ptrs[] = {G->d_idx, G->d_stored, G->d_res, G->d_jf, G->d_jr, G->d_small};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (G->h_small) (void)hipHostFree(G->h_small);
@@ -403,9 +413,9 @@ void cox_reg_destroy(cox_reg_t* G) {
 int cox_reg_evaluate(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double* residuals,
                      double* jac_ref, double* jac_read) {
   COX_ENTRY();
-  if (!G || !pose_ref || !pose_read || n_res > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  if (!G || !pose_ref || !pose_read || n_res > 0x7FFFFFFFull || G->pending) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(G->reading->device));
-  if (n_res == 0) return sample_idx || G->ref->n == 0 ? COX_OK : COX_ERR_INVALID_ARG;
+  if (n_res == 0) return sample_idx || G->has_stored || G->ref->n == 0 ? COX_OK : COX_ERR_INVALID_ARG;
   const u32* d_idx;
   COX_TRY(stage_samples(G, sample_idx, n_res, &d_idx));
   const u32 n = static_cast<u32>(n_res);
@@ -437,16 +447,32 @@ int cox_reg_evaluate(cox_reg_t* G, const double pose_ref[4], const double pose_r
   return COX_OK;
 }
 
-int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double H[64],
-                      double b[8], double* cost, uint64_t* n_corr) {
+int cox_reg_set_samples(cox_reg_t* G, const uint32_t* sample_idx, uint64_t n_res) {
   COX_ENTRY();
-  if (!G || !pose_ref || !pose_read || !H || !b || !cost || n_res > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  if (!G || n_res > 0x7FFFFFFFull || G->pending) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(G->reading->device));
-  for (int i = 0; i < 64; ++i) H[i] = 0.0;
-  for (int i = 0; i < 8; ++i) b[i] = 0.0;
-  *cost = 0.0;
-  if (n_corr) *n_corr = 0;
-  if (n_res == 0) return sample_idx || G->ref->n == 0 ? COX_OK : COX_ERR_INVALID_ARG;
+  G->has_stored = false;
+  G->stored_samples = 0;
+  if (!sample_idx) return COX_OK;  // back to "all points in order"
+  for (uint64_t i = 0; i < n_res; ++i)
+    if (sample_idx[i] >= G->ref->n) return COX_ERR_INVALID_ARG;
+  COX_TRY(dev_grow(&G->d_stored, &G->stored_cap, std::max<uint64_t>(n_res, 1)));
+  COX_HIP(hipMemcpy(G->d_stored, sample_idx, sizeof(u32) * n_res, hipMemcpyHostToDevice));
+  G->has_stored = true;
+  G->stored_samples = n_res;
+  return COX_OK;
+}
+
+int cox_reg_normal_eq_begin(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res) {
+  COX_ENTRY();
+  if (!G || !pose_ref || !pose_read || n_res > 0x7FFFFFFFull || G->pending) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(G->reading->device));
+  G->pending_n = n_res;
+  if (n_res == 0) {
+    if (!(sample_idx || G->has_stored || G->ref->n == 0)) return COX_ERR_INVALID_ARG;
+    G->pending = true;
+    return COX_OK;
+  }
   const u32* d_idx;
   COX_TRY(stage_samples(G, sample_idx, n_res, &d_idx));
   const u32 n = static_cast<u32>(n_res);
@@ -461,7 +487,20 @@ int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_
   hipLaunchKernelGGL(k_reg_reduce_partials, dim3(1), dim3(256), 0, s, G->d_small + kPartial, nb, G->d_small);
   COX_HIP(hipEventRecord(G->ev1, s));
   COX_HIP(hipMemcpyAsync(G->h_small, G->d_small, sizeof(double) * kPartial, hipMemcpyDeviceToHost, s));
-  COX_HIP(hipStreamSynchronize(s));
+  G->pending = true;
+  return COX_OK;
+}
+
+int cox_reg_normal_eq_finish(cox_reg_t* G, double H[64], double b[8], double* cost, uint64_t* n_corr) {
+  if (!G || !H || !b || !cost || !G->pending) return COX_ERR_INVALID_ARG;
+  G->pending = false;
+  for (int i = 0; i < 64; ++i) H[i] = 0.0;
+  for (int i = 0; i < 8; ++i) b[i] = 0.0;
+  *cost = 0.0;
+  if (n_corr) *n_corr = 0;
+  if (G->pending_n == 0) return COX_OK;
+  COX_HIP(hipSetDevice(G->reading->device));
+  COX_HIP(hipStreamSynchronize(G->stream));
   COX_HIP(hipGetLastError());
   float ms = 0.0f;
   if (hipEventElapsedTime(&ms, G->ev0, G->ev1) == hipSuccess) {
@@ -470,7 +509,7 @@ int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_
   }
   const double* D = G->h_small;  // D[row * 16 + col] = sum_p x[row] x[col]
   const double sum_w = D[9 * 16 + 10];
-  const double scale = sum_w > 0.0 ? static_cast<double>(n_res) / sum_w : 0.0;
+  const double scale = sum_w > 0.0 ? static_cast<double>(G->pending_n) / sum_w : 0.0;
   const double s2 = scale * scale;
   for (int r = 0; r < 8; ++r) {
     for (int c = 0; c < 8; ++c) H[8 * r + c] = D[r * 16 + c] * s2;
@@ -479,6 +518,13 @@ int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_
   *cost = 0.5 * D[8 * 16 + 8] * s2;
   if (n_corr) *n_corr = static_cast<uint64_t>(D[9 * 16 + 11] + 0.5);
   return COX_OK;
+}
+
+int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double H[64],
+                      double b[8], double* cost, uint64_t* n_corr) {
+  if (!G || !pose_ref || !pose_read || !H || !b || !cost) return COX_ERR_INVALID_ARG;
+  COX_TRY(cox_reg_normal_eq_begin(G, pose_ref, pose_read, sample_idx, n_res));
+  return cox_reg_normal_eq_finish(G, H, b, cost, n_corr);
 }
 
 int cox_reg_kernel_time(cox_reg_t* G, double* ms, uint64_t* launches, int reset) {

@@ -190,6 +190,15 @@ int cox_reg_evaluate(cox_reg_t* reg, const double pose_ref[4], const double pose
  * 74 numbers cross PCIe. */
 int cox_reg_normal_eq(cox_reg_t* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res,
                       double H[64], double b[8], double* cost, uint64_t* n_corr);
+/* The same evaluation without waiting for it: begin enqueues the kernels on the handle's own stream, finish waits and
+ * returns the 74 numbers.  A pose-graph evaluation begins all of its constraints (their kernels overlap on the GPU),
+ * then finishes them: one round of launch + PCIe latency per solver iteration instead of one per constraint.  One
+ * begin may be outstanding per handle. */
+int cox_reg_normal_eq_begin(cox_reg_t* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res);
+int cox_reg_normal_eq_finish(cox_reg_t* reg, double H[64], double b[8], double* cost, uint64_t* n_corr);
+/* Keep a set of sample indices on the GPU: later calls that pass sample_idx = NULL with this n_res use them (no 4*n_res
+ * byte upload per evaluation).  sample_idx = NULL here drops the stored set (NULL then means "all points in order" again). */
+int cox_reg_set_samples(cox_reg_t* reg, const uint32_t* sample_idx, uint64_t n_res);
 /* HIP-event time of the registration kernel since last reset (bench.py) */
 int cox_reg_kernel_time(cox_reg_t* reg, double* ms, uint64_t* launches, int reset);
 

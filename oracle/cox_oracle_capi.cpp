@@ -26,6 +26,10 @@ struct coxo_reg {
   const coxo_regpoints* ref;
   const coxo_layer* reading;
   RegConfig cfg;
+  std::vector<uint32_t> stored;  // cox_reg_set_samples
+  bool has_stored = false, pending = false;
+  double H[64], b[8], cost = 0.0;
+  uint64_t n_corr = 0;
 };
 
 static TsdfConfig toCfg(const cox_tsdf_config* c) {
@@ -287,6 +291,10 @@ void coxo_reg_destroy(coxo_reg* r) { delete r; }
 static int regRun(coxo_reg* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double* residuals,
                   double* jf, double* jr, double* H, double* b, double* cost, uint64_t* n_corr) {
   const size_t npts = reg->ref->pts.size();
+  if (!sample_idx && reg->has_stored) {  // cox_reg_set_samples
+    if (n_res != reg->stored.size()) return COX_ERR_INVALID_ARG;
+    sample_idx = reg->stored.data();
+  }
   if (!sample_idx && n_res != npts) return COX_ERR_INVALID_ARG;
   const RelPose P = makeRelPose(pose_ref, pose_read);
   double sum_w = 0.0;
@@ -337,6 +345,34 @@ int coxo_reg_evaluate(coxo_reg* reg, const double pose_ref[4], const double pose
 int coxo_reg_normal_eq(coxo_reg* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res, double H[64],
                        double b[8], double* cost, uint64_t* n_corr) {
   return regRun(reg, pose_ref, pose_read, sample_idx, n_res, nullptr, nullptr, nullptr, H, b, cost, n_corr);
+}
+// begin / finish: the oracle has nothing to overlap, begin computes and finish hands the result over
+int coxo_reg_normal_eq_begin(coxo_reg* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res) {
+  if (!reg || reg->pending) return COX_ERR_INVALID_ARG;
+  const int rc = regRun(reg, pose_ref, pose_read, sample_idx, n_res, nullptr, nullptr, nullptr, reg->H, reg->b, &reg->cost, &reg->n_corr);
+  reg->pending = rc == COX_OK;
+  return rc;
+}
+int coxo_reg_normal_eq_finish(coxo_reg* reg, double H[64], double b[8], double* cost, uint64_t* n_corr) {
+  if (!reg || !reg->pending) return COX_ERR_INVALID_ARG;
+  reg->pending = false;
+  for (int i = 0; i < 64; ++i) H[i] = reg->H[i];
+  for (int i = 0; i < 8; ++i) b[i] = reg->b[i];
+  *cost = reg->cost;
+  if (n_corr) *n_corr = reg->n_corr;
+  return COX_OK;
+}
+int coxo_reg_set_samples(coxo_reg* reg, const uint32_t* sample_idx, uint64_t n_res) {
+  if (!reg || reg->pending) return COX_ERR_INVALID_ARG;
+  reg->has_stored = sample_idx != nullptr;
+  reg->stored.assign(sample_idx ? sample_idx : nullptr, sample_idx ? sample_idx + n_res : nullptr);
+  for (uint32_t i : reg->stored)
+    if (i >= reg->ref->pts.size()) {
+      reg->has_stored = false;
+      reg->stored.clear();
+      return COX_ERR_INVALID_ARG;
+    }
+  return COX_OK;
 }
 
 }  // extern "C"

@@ -90,6 +90,39 @@ def test_sampled_evaluate_and_normal_equations(hip, oracle, submaps):
     assert np.array_equal(Hh, H2) and np.array_equal(bh, b2) and ch == c2
 
 
+def test_begin_finish_and_stored_samples_give_the_same_numbers(hip, oracle, submaps):
+    """The split form a pose-graph evaluation uses (begin all constraints, then collect) and sample indices kept on the
+    GPU: identical to the one-call form, on both engines."""
+    from coxgraph_amd.capi import CoxError
+    pts, lb, lh = submaps
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, len(pts), size=4000).astype(np.uint32)
+    poses = [(np.array([0.0, 0, 0, 0]), np.array([0.05, -0.03, 0.02, 0.02])), (np.array([0.1, 0.2, 0.0, -0.01]), np.array([0.12, 0.18, 0.01, 0.0])),
+             (np.zeros(4), np.zeros(4))]
+    for eng, layer in ((hip, lh), (oracle, lb)):
+        regs = [Registration(eng, RegPoints(eng, pts), layer, 0.05) for _ in poses]
+        want = [g.normal_eq(pr, pd, idx) for g, (pr, pd) in zip(regs, poses)]
+        for g in regs:
+            g.set_samples(idx)
+        for g, (pr, pd) in zip(regs, poses):
+            g.normal_eq_begin(pr, pd)             # stored samples, nothing waited for yet
+        got = [g.normal_eq_finish() for g in regs]
+        for (H0, b0, c0, n0), (H1, b1, c1, n1) in zip(want, got):
+            assert np.array_equal(H0, H1) and np.array_equal(b0, b1) and c0 == c1 and n0 == n1
+        r0, _, _ = regs[0].evaluate(*poses[0], idx)
+        r1, _, _ = regs[0].evaluate(*poses[0])    # stored samples through the Ceres-shaped call as well
+        assert np.array_equal(r0, r1)
+        regs[0].normal_eq_begin(*poses[0])
+        with pytest.raises(CoxError):             # one begin outstanding per handle
+            regs[0].normal_eq_begin(*poses[0])
+        regs[0].normal_eq_finish()
+        with pytest.raises(CoxError):
+            regs[0].normal_eq_finish()
+        regs[0].set_samples(None)                 # back to "all points in order"
+        ra, _, _ = regs[0].evaluate(*poses[0])
+        assert len(ra) == len(pts)
+
+
 def test_jacobian_against_central_differences_on_gpu(hip, oracle, submaps):
     gh, _, pts = _pair(hip, oracle, submaps)
     pr, pd = np.array([0.01, 0.02, -0.01, 0.01]), np.array([0.03, -0.02, 0.01, -0.01])
