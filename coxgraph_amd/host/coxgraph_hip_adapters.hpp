@@ -315,18 +315,23 @@ class RegistrationCostFunction {
   }
   int num_residuals() const { return static_cast<int>(sample_idx_.empty() ? n_ : sample_idx_.size()); }
   // the weighted sampler's draws (sampling_ratio > 0); empty = every point once (sampling_ratio = -1)
-  void setSampleIndices(const std::vector<uint32_t>& idx) { sample_idx_ = idx; }
+  // (the indices are uploaded once and stay on the GPU)
+  void setSampleIndices(const std::vector<uint32_t>& idx) {
+    sample_idx_ = idx;
+    check(cox_reg_set_samples(reg_, idx.empty() ? nullptr : idx.data(), idx.size()), "setSampleIndices");
+  }
   // ceres::CostFunction::Evaluate: parameters = {reference pose (x,y,z,yaw), reading pose}, jacobians row-major N x 4
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
-    const uint32_t* si = sample_idx_.empty() ? nullptr : sample_idx_.data();
-    return cox_reg_evaluate(reg_, parameters[0], parameters[1], si, num_residuals(), residuals, jacobians ? jacobians[0] : nullptr,
+    return cox_reg_evaluate(reg_, parameters[0], parameters[1], nullptr, num_residuals(), residuals, jacobians ? jacobians[0] : nullptr,
                             jacobians ? jacobians[1] : nullptr) == COX_OK;
   }
   // fused Gauss-Newton block: H = J^T J (8x8), b = J^T r, cost = |r|^2 / 2
   bool NormalEquations(const double ref[4], const double read[4], double H[64], double b[8], double* cost) const {
-    const uint32_t* si = sample_idx_.empty() ? nullptr : sample_idx_.data();
-    return cox_reg_normal_eq(reg_, ref, read, si, num_residuals(), H, b, cost, nullptr) == COX_OK;
+    return cox_reg_normal_eq(reg_, ref, read, nullptr, num_residuals(), H, b, cost, nullptr) == COX_OK;
   }
+  // the same in two halves: a solver begins every constraint of an evaluation, then collects them (the kernels overlap)
+  bool BeginNormalEquations(const double ref[4], const double read[4]) const { return cox_reg_normal_eq_begin(reg_, ref, read, nullptr, num_residuals()) == COX_OK; }
+  bool FinishNormalEquations(double H[64], double b[8], double* cost) const { return cox_reg_normal_eq_finish(reg_, H, b, cost, nullptr) == COX_OK; }
 
  private:
   size_t n_;
