@@ -208,6 +208,7 @@ class Integrator:
         return s.asdict()
 
     def set_profiling(self, on=True):
+        """0 / False = off, n >= 1 = HIP-event timing of the merge and apply kernels of every n-th frame."""
         self.eng.check(self.eng.fn("integrator_set_profiling")(self.h, C.c_int(int(on))), "integrator_set_profiling")
 
     def stage_times(self, reset=False):

@@ -1264,6 +1264,7 @@ struct cox_integrator {
   hipGraphExec_t graphs[4][kFrameSets] = {};
   // timing of individual kernels (bench roofline); forces eager launches
   bool profiling = false;
+  u32 profile_every = 1;  // time the kernels of every n-th frame
   std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events, merge_events;
   double apply_ms = 0.0, merge_ms = 0.0;
   uint64_t apply_launches = 0, merge_launches = 0;
@@ -1475,13 +1476,14 @@ static int stage_a2(const StageCtx& c, hipStream_t s) {
     exclusive_scan_u32(B.head, B.head, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
     hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
     hipEvent_t m0 = nullptr, m1 = nullptr;
-    if (I->profiling) {
+    const bool timed = I->profiling && (I->frame_no % I->profile_every == 0);
+    if (timed) {
       COX_HIP(hipEventCreate(&m0));
       COX_HIP(hipEventCreate(&m1));
       COX_HIP(hipEventRecord(m0, s));
     }
     hipLaunchKernelGGL(k_bundle_merge, dim3(4096), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt);
-    if (I->profiling) {
+    if (timed) {
       COX_HIP(hipEventRecord(m1, s));
       I->merge_events.emplace_back(m0, m1);
     }
@@ -1552,7 +1554,8 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &F.cnt->n_records};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (I->profiling) {
+  const bool timed = I->profiling && (I->frame_no % I->profile_every == 0);
+  if (timed) {
     COX_HIP(hipEventCreate(&e0));
     COX_HIP(hipEventCreate(&e1));
     COX_HIP(hipEventRecord(e0, s));
@@ -1560,7 +1563,7 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
   hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
                      I->layer->d_err);
-  if (I->profiling) {
+  if (timed) {
     COX_HIP(hipEventRecord(e1, s));
     I->apply_events.emplace_back(e0, e1);
   }
@@ -1988,7 +1991,8 @@ int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
 int cox_integrator_set_profiling(cox_integrator_t* I, int on) {
   COX_ENTRY();
   if (!I) return COX_ERR_INVALID_ARG;
-  I->profiling = on != 0;
+  I->profiling = on > 0;
+  I->profile_every = on > 1 ? static_cast<u32>(on) : 1u;
   return COX_OK;
 }
 

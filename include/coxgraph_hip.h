@@ -141,7 +141,8 @@ int cox_integrate_depth_dev(cox_integrator_t* integ, const float T_G_C[7], const
 /* wait for the handle's stream; returns any deferred device-side error (pool exhausted, ...) */
 int cox_integrator_sync(cox_integrator_t* integ);
 int cox_integrator_last_stats(cox_integrator_t* integ, cox_frame_stats* stats);
-/* switch HIP-event timing of the TSDF update ("apply") stage on/off (off by default) */
+/* HIP-event timing of the bundle-merge and TSDF-update ("apply") kernels on the streams they run on: 0 = off (default),
+ * n >= 1 = time the kernels of every n-th frame */
 int cox_integrator_set_profiling(cox_integrator_t* integ, int on);
 /* HIP-event time of the dominant kernel over the calls since the last reset (bench.py roofline):
  * accumulated milliseconds and launch count of the TSDF update ("apply") stage */
