@@ -249,6 +249,47 @@ def main():
                "two_stage_solve_ms": solve_ms, "solve_evaluations": second["evaluations"],
                "solved_pose_error": [float(x) for x in pg.getPoseMap()[1]]}
 
+    # ---- N > 1: the server's inter-robot registration, constraints dealt over the ranks, one all-reduce per evaluation ----
+    # (SURVEY.md section 8e / BASELINE configs[2], [4]): all pairs of 8 submaps = 28 forced registration constraints; every
+    # rank evaluates its share against its own client's map (begin all, then collect) and the packed (4N)^2 + 4N + 1
+    # doubles are summed with ONE all-reduce (RCCL when the backend is nccl).  Max over ranks, like the fusion timing.
+    dist_reg = None
+    if world > 1 and args.reg_iters > 0:
+        from coxgraph_amd.posegraph import PoseGraph, RegistrationConstraint
+        trunc = cfg.default_truncation_distance
+        ref = RegPoints.from_layer(eng, layer, 1.0, trunc)
+        rng = np.random.default_rng(7 + rank)
+        n_res = int(0.3 * ref.n)
+        sidx = rng.integers(0, max(ref.n, 1), size=n_res).astype(np.uint32)
+        pg = PoseGraph()
+        n_nodes = 8
+        for k in range(n_nodes):
+            pg.add_node(k, [0.01 * k, -0.005 * k, 0.002 * k, 0.001 * k], constant=(k == 0))
+        pairs = [(a, b) for a in range(n_nodes) for b in range(a + 1, n_nodes)]
+        for k, (a, b) in enumerate(pairs):
+            if k % world == rank:
+                g = Registration(eng, ref, layer)
+                g.set_samples(sidx)
+                pg.reg.append(RegistrationConstraint(a, b, g))
+            else:
+                pg.reg.append(None)  # another rank's constraint: never touched here
+        poses = {k: v.copy() for k, v in pg.poses.items()}
+        pg.build(poses, group=dist.group.WORLD)
+        dist.barrier()
+        n_eval = max(4, args.reg_iters // 10)
+        t4 = time.perf_counter()
+        for _ in range(n_eval):
+            cost, _, _, _ = pg.build(poses, group=dist.group.WORLD)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt4 = time.perf_counter() - t4
+        tt = torch.tensor([dt4], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt4 = float(tt.item())
+        dist_reg = {"pose_graph_evaluations_per_s": n_eval / dt4, "registrations_per_s": n_eval * len(pairs) / dt4, "constraints": len(pairs),
+                    "residuals_per_constraint": n_res, "all_reduce_doubles": (4 * (n_nodes - 1)) ** 2 + 4 * (n_nodes - 1) + 1,
+                    "backend": "rccl" if backend == "nccl" else backend, "cost": cost}
+
     # ---- the reference's configured method (`method: "fast"`, tsdf_server_euroc.yaml:6) on the same stream, for context ----
     other = None
     if rank == 0 and world == 1 and args.method != "fast" and args.fast_frames > 0:
@@ -290,7 +331,7 @@ def main():
                                    f"{args.method} integrator semantics (bit-exact vs CPU oracle), points resident in HBM",
                        "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
             "frame_stats_mean": {k: v / max(args.steps, 1) for k, v in stats_sum.items()},
-            "roofline": roofline, "cpu_baseline": cpu, "registration": reg, "other_methods": other,
+            "roofline": roofline, "cpu_baseline": cpu, "registration": reg, "distributed_registration": dist_reg, "other_methods": other,
         }
         print(json.dumps(line))
     if world > 1:
