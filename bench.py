@@ -87,10 +87,12 @@ def main():
     torch.cuda.set_device(dev_index)
     backend = os.environ.get("COX_DIST_BACKEND", "nccl")  # "gloo" to rehearse N > 1 on a single-GPU box
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=180)  # a rank that dies must not leave the others waiting for the default 10 min
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     local_rank = dev_index
 
     import coxgraph_amd
