@@ -603,8 +603,12 @@ __device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /
   if (g0 > kAxisCap || g1 > kAxisCap || g2 > kAxisCap || ns > 3 * kAxisCap) return false;
   const u32 L = ns - 1;
   if (lane < 3) {
-    float T = (lane == 0) ? d0.t_next[0] : (lane == 1) ? d0.t_next[1] : d0.t_next[2];
-    const float st = (lane == 0) ? d0.t_step[0] : (lane == 1) ? d0.t_step[1] : d0.t_step[2];
+    // the per-axis values are picked with selects on opaque copies: left alone, the compiler turns "lane == 0 ? a[0] :
+    // lane == 1 ? a[1] : a[2]" into a[lane] and moves the whole Dda into scratch memory (72 B per lane written per ray)
+    float tn0 = d0.t_next[0], tn1 = d0.t_next[1], tn2 = d0.t_next[2], ts0 = d0.t_step[0], ts1 = d0.t_step[1], ts2 = d0.t_step[2];
+    asm volatile("" : "+v"(tn0), "+v"(tn1), "+v"(tn2), "+v"(ts0), "+v"(ts1), "+v"(ts2));
+    float T = (lane == 0) ? tn0 : (lane == 1) ? tn1 : tn2;
+    const float st = (lane == 0) ? ts0 : (lane == 1) ? ts1 : ts2;
     const u32 g = (lane == 0) ? g0 : (lane == 1) ? g1 : g2;
     float* row = tl + lane * kAxisCap;
     for (u32 j = 0; j < g; ++j) {
