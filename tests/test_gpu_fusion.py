@@ -259,25 +259,27 @@ def test_layer_wire_roundtrip_merge_clear(hip, oracle):
     compare_layers(lh, la)
 
 
-def test_depth_front_end_matches_point_path(hip):
+@pytest.mark.parametrize("method", ["merged", "fast"])
+def test_depth_front_end_matches_point_path(hip, method):
     import torch
     T, pts, rgba, depth = synth.make_frame(2, nan_fraction=0.02)
     cfg = hip.default_config(**synth.integrator_overrides(0.05))
     l1 = Layer(hip, 0.05, capacity_blocks=8192)
     l2 = Layer(hip, 0.05, capacity_blocks=8192)
-    Integrator(hip, l1, cfg, "merged").integrate_points(T, pts, rgba)
+    Integrator(hip, l1, cfg, method).integrate_points(T, pts, rgba)
     d = torch.from_numpy(depth).cuda()
     c = torch.from_numpy(synth.frame_colors()).cuda()
-    i2 = Integrator(hip, l2, cfg, "merged")
+    i2 = Integrator(hip, l2, cfg, method)
     i2.integrate_depth_dev(T, d.data_ptr(), c.data_ptr(), 640, 480, synth.INTRINSICS[(640, 480)])
     i2.sync()
     rep = compare_layers(l2, l1)
     assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0
 
 
-def test_results_are_reproducible_run_to_run(hip):
-    a, _, _ = run_frames(hip, method="merged", voxel=0.05, frames=[0, 1, 2], capacity_blocks=8192)
-    b, _, _ = run_frames(hip, method="merged", voxel=0.05, frames=[0, 1, 2], capacity_blocks=8192)
+@pytest.mark.parametrize("method", ["merged", "fast"])
+def test_results_are_reproducible_run_to_run(hip, method):
+    a, _, _ = run_frames(hip, method=method, voxel=0.05, frames=[0, 1, 2], capacity_blocks=8192)
+    b, _, _ = run_frames(hip, method=method, voxel=0.05, frames=[0, 1, 2], capacity_blocks=8192)
     ia, va = a.download()
     ib, vb = b.download()
     assert np.array_equal(ia, ib) and np.array_equal(va, vb)

@@ -206,13 +206,13 @@ def test_gpu_kat_cases_match_oracle(hip, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["merged", "simple"])
+@pytest.mark.parametrize("method", ["merged", "simple", "fast"])  # "fast" is what coxgraph/config/tsdf_recover.yaml:6 configures
 def test_gpu_process_mesh_matches_oracle(hip, oracle, method):
     m = synth.make_wall_mesh(seed=5, n_frames=12)
     msg = MeshMsg(m["block_edge_length"], m["blocks"], m["trajectory"])
     layers = {}
     for name, eng in (("hip", hip), ("oracle", oracle)):
-        cfg = eng.default_config(**synth.integrator_overrides(0.05))
+        cfg = eng.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
         layer = Layer(eng, 0.05)
         integ = Integrator(eng, layer, cfg, method)
         # something already in the layer: processMesh starts with removeAllBlocks
