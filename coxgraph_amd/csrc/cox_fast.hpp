@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict
 // ---- observed set -------------------------------------------------------------------------------------------------
 // wave = ray: every voxel the ray would visit if nothing stopped it, in walking order (parallel DDA of the merged
 // integrator's bundles, wave_ray_path; sequential on lane 0 for the rays that one does not cover)
+template <u32 kAxisCap>
 __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ vhash, u32* __restrict__ vkey,
                                                      u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ reach, u32 vcap, Counters* cnt) {
   const FrameParams P = *Pp;
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restri
     const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
     Dda d;
     dda_setup(d, P, pg, (uniform_u32(R.flags[r]) & 2u) != 0);
-    if (wave_ray_path(d, ns, tl, path, lane)) {
+    if (wave_ray_path<kAxisCap>(d, ns, tl, path, lane)) {
       for (u32 s = lane; s < ns; s += 64) {
         const u32 p = path[s];
         const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];

@@ -560,7 +560,9 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
 //     binary search; the same counts are the voxel's offset from the start voxel;
 //   - rays the argument does not cover (a zero ray component gives -inf / NaN times, very long rays, or a walk
 //     that would need more crossings of one axis than were generated) fall back to the sequential walk on lane 0.
-constexpr u32 kAxisCap = 512;
+// per-axis crossing capacity of the parallel DDA: two instantiations, the small one (12 KB of LDS per workgroup instead
+// of 48 KB, so every ray of a frame is resident at once) whenever no ray of the configuration can cross more planes
+constexpr u32 kAxisCapSmall = 128, kAxisCapLarge = 512;
 constexpr u32 kRayFallback = 4u;  // ray flag
 
 __device__ __forceinline__ u32 pack_path(u32 jx, u32 jy, u32 jz) { return jx | (jy << 10) | (jz << 20); }
@@ -597,6 +599,7 @@ __device__ __forceinline__ int dda_step_axis(Dda& d) {
 }
 // Fills path[0, ns) (LDS, this wave's) with the packed per-axis crossing counts of every step.  Returns false
 // when the ray needs the sequential fallback (nothing usable was written).
+template <u32 kAxisCap>
 __device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /*[3][kAxisCap]*/, u32* path, u32 lane) {
   if (d0.sgn[0] == 0 || d0.sgn[1] == 0 || d0.sgn[2] == 0) return false;
   const u32 g0 = d0.n_axis[0] + 2, g1 = d0.n_axis[1] + 2, g2 = d0.n_axis[2] + 2;
@@ -668,6 +671,7 @@ __device__ __forceinline__ void touch_block(const FrameParams& P, const LayerVie
   }
 }
 
+template <u32 kAxisCap>
 __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ touched_slots, u32* __restrict__ path_out,
                                                     u32 rec_cap, Counters* cnt, u32* layer_err, const u64* __restrict__ fh_keys, u32 fh_mask) {
   const FrameParams P = *Pp;
@@ -689,7 +693,7 @@ __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restric
     const u64 own_key = P.anti_grazing ? R.key[r] : 0ull;
     Dda d;
     dda_setup(d, P, pg, clearing);
-    const bool par = wave_ray_path(d, ns, tl, path, lane);
+    const bool par = wave_ray_path<kAxisCap>(d, ns, tl, path, lane);
     if (lane == 0) R.flags[r] = par ? (flags & ~kRayFallback) : (flags | kRayFallback);
     if (par) {
       const u32 off = uniform_u32(R.rec_off[r]);
@@ -1252,6 +1256,7 @@ struct cox_integrator {
   FrameParams* h_params = nullptr;  // pinned, kFrameSets entries
   u32 pcap = 0, rcap = 0, fh_cap = 0;
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
+  bool small_axis_cap = false;  // no ray can cross more than kAxisCapSmall - 2 planes of one axis
   float* own_xyz = nullptr;  // staging for host / depth inputs
   uint8_t* own_rgba = nullptr;
   u32* depth_flag = nullptr;
@@ -1360,6 +1365,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   // records: the worst case (every ray at maximum length) always fits, so a frame can never overflow
   // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
   I->steps_max = max_steps_per_ray(I);
+  I->small_axis_cap = (I->steps_max - 1) / 3 + 2 <= kAxisCapSmall;  // steps_max = 3 * (planes per axis bound) + 1
   const u64 want = static_cast<u64>(cap) * I->steps_max;
   const u64 limit = 0x7FFFFFF0ull;
   const u32 rcap = static_cast<u32>(std::min(want, limit));
@@ -1535,8 +1541,12 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
     exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_records, I->scanws_b, s);
   if (merged) {
     // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
-    hipLaunchKernelGGL(k_touch_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt, I->layer->d_err, F.fh_keys,
-                       fh_mask);
+    if (I->small_axis_cap)
+      hipLaunchKernelGGL(k_touch_wave<kAxisCapSmall>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
+                         I->layer->d_err, F.fh_keys, fh_mask);
+    else
+      hipLaunchKernelGGL(k_touch_wave<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
+                         I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
                        F.fh_keys, fh_mask);
   } else {
@@ -1642,7 +1652,10 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, F.cnt);
   // candidate visits: every voxel of every ray's whole walk, sorted by slot of the observed set
   exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
-  hipLaunchKernelGGL(k_fast_visits, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
+  if (I->small_axis_cap)
+    hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
+  else
+    hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
   const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21), kFastSlotBits,
                                       false, 2, I->sort_rec, nullptr, s);
   hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
