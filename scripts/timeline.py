@@ -4,12 +4,19 @@ over the last `frac` of the run (the timed region of bench.py)."""
 import csv, sys, glob, collections
 path = sys.argv[1]
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-f = glob.glob(path + "/*/*kernel_trace.csv")[0]
+f = path if path.endswith(".csv") else glob.glob(path + "/*/*kernel_trace.csv")[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40], r["Queue_Id"]) for r in csv.DictReader(open(f))]
 rows.sort()
-t0, t1 = rows[0][0], max(r[1] for r in rows)
-cut = t1 - (t1 - t0) * frac
-rows = [r for r in rows if r[0] >= cut]
+# window: the middle half of the fusion frames (between the 25 % and 75 % launch of the layer-update kernel), so that
+# warm-up, the registration section and the CPU baseline of bench.py stay out of the statistics
+marks = [r[0] for r in rows if r[2].startswith("k_apply_eval")]
+if len(marks) >= 8:
+    lo, hi = marks[len(marks) // 4], marks[3 * len(marks) // 4]
+    rows = [r for r in rows if lo <= r[0] < hi]
+else:
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    cut = t1 - (t1 - t0) * frac
+    rows = [r for r in rows if r[0] >= cut]
 span = max(r[1] for r in rows) - rows[0][0]
 ev = []
 for s, e, _, _ in rows:
