@@ -1070,15 +1070,12 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
   const u32 lane = lane_id();
   const u32 n_waves = (n + 63) >> 6;
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  // every record wave with a back piece owns one long segment; 64 record waves are inspected per step
-  for (u32 wb0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6; wb0 < n_waves; wb0 += waves_total << 6) {
-    const u32 pbl = (wb0 + lane < n_waves) ? piece_back[wb0 + lane] : 0u;
-    u64 todo = __ballot(pbl != 0u);
-    while (todo) {
-      const u32 bit = static_cast<u32>(__ffsll(static_cast<long long>(todo))) - 1u;
-      todo &= todo - 1ull;
-      const u32 w0 = wb0 + bit;
-      const u32 pb = static_cast<u32>(__builtin_amdgcn_readlane(pbl, bit));
+  // every record wave with a back piece owns one long segment: one wave of this kernel per record wave, so that the long
+  // segments of a frame (they cluster: the voxels of the cone in front of the sensor) are folded side by side
+  for (u32 w0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); w0 < n_waves; w0 += waves_total) {
+    {
+      const u32 pb = uniform_u32(piece_back[w0]);
+      if (pb == 0u) continue;
       const u32 count0 = pb & 127u;
       const u32 start = (w0 << 6) + 64u - count0;
       const VoxelRef vr = locate_voxel(L, touched_slots, uniform_u32(rec_key[start]));
@@ -1575,7 +1572,7 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
     COX_HIP(hipEventRecord(e0, s));
   }
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
-  hipLaunchKernelGGL(k_apply_long, dim3(256), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
+  hipLaunchKernelGGL(k_apply_long, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
                      I->layer->d_err);
   if (timed) {
     COX_HIP(hipEventRecord(e1, s));
