@@ -503,13 +503,25 @@ __global__ void __launch_bounds__(256) k_touch(const FrameParams* __restrict__ P
   }
 }
 
+// every emit kernel starts by publishing, per block touched this frame, what the update kernels need of it
+__device__ __forceinline__ void fill_ord_info(const LayerView& L, const u32* __restrict__ touched_slots, int4* __restrict__ ord_info, u32 n_touched) {
+  for (u32 ord = blockIdx.x * blockDim.x + threadIdx.x; ord < n_touched; ord += gridDim.x * blockDim.x) {
+    const u32 slot = touched_slots[ord];
+    int bx, by, bz;
+    unpack_key(L.ht_keys[slot], &bx, &by, &bz);
+    ord_info[ord] = make_int4(bx * 16, by * 16, bz * 16, static_cast<int>(L.ht_vals[slot]));
+  }
+}
+
 // ---- emit: (voxel id, ray id) records, ray-major ------------------------------------------------
 // voxel id = ordinal of the block within this frame << 12 | linear voxel index.  Also publishes the key
 // width the record sort needs.
 __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ rec_key, u32* __restrict__ rec_ray, u32 rec_cap,
-                                              Counters* cnt, SortInfo* sort_info, const u64* __restrict__ fh_keys, u32 fh_mask) {
+                                              Counters* cnt, SortInfo* sort_info, const u64* __restrict__ fh_keys, u32 fh_mask, const u32* __restrict__ touched_slots,
+                                              int4* __restrict__ ord_info) {
   const FrameParams P = *Pp;
   const u32 n_slots = cnt->n_ray_slots;
+  fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
     u32 bits = 12;
@@ -736,9 +748,10 @@ __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restric
 
 __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ path_in, u32* __restrict__ rec_key,
                                                    u32* __restrict__ rec_ray, u32 rec_cap, Counters* cnt, SortInfo* sort_info,
-                                                   const u64* __restrict__ fh_keys, u32 fh_mask) {
+                                                   const u64* __restrict__ fh_keys, u32 fh_mask, const u32* __restrict__ touched_slots, int4* __restrict__ ord_info) {
   const FrameParams P = *Pp;
   const u32 n_slots = uniform_u32(cnt->n_ray_slots);
+  fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
   const bool overflow = uniform_u32(cnt->n_records) > rec_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
@@ -844,16 +857,16 @@ struct VoxelRef {
   int gx, gy, gz;
   bool ok;
 };
-__device__ __forceinline__ VoxelRef locate_voxel(const LayerView& L, const u32* touched_slots, u32 vid) {
+// one 16-B gather per record instead of three dependent ones (ordinal -> hash slot -> block key / pool index): the emit
+// kernel leaves (16 * block index, pool index) of every block touched this frame in ord_info
+__device__ __forceinline__ VoxelRef locate_voxel(const LayerView& L, const int4* __restrict__ ord_info, u32 vid) {
   VoxelRef v;
   const u32 ord = vid >> 12, lin = vid & 4095u;
-  const u32 slot = touched_slots[ord];
-  const u32 pool = L.ht_vals[slot];
-  int bx, by, bz;
-  unpack_key(L.ht_keys[slot], &bx, &by, &bz);
-  v.gx = bx * 16 + static_cast<int>(lin & 15u);
-  v.gy = by * 16 + static_cast<int>((lin >> 4) & 15u);
-  v.gz = bz * 16 + static_cast<int>(lin >> 8);
+  const int4 b = ord_info[ord];
+  const u32 pool = static_cast<u32>(b.w);
+  v.gx = b.x + static_cast<int>(lin & 15u);
+  v.gy = b.y + static_cast<int>((lin >> 4) & 15u);
+  v.gz = b.z + static_cast<int>(lin >> 8);
   v.ok = pool != kInvalid;
   v.ptr = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + lin) * kWordsPerVoxel;
   return v;
@@ -865,7 +878,16 @@ __device__ __forceinline__ bool foldable_update(const FrameParams& P, float sdf,
   return saturating_update(P, sdf, uw) && uw == truncf(uw) && uw < 65536.0f;
 }
 
-__global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
+// fold a run of foldable pieces with total integer weight wsum; false when the voxel state does not allow it
+__device__ __forceinline__ bool fold_pieces(const FrameParams& P, Voxel& v, u32 wsum) {
+  if (v.d != P.trunc) return false;
+  if (v.w >= P.max_weight) return true;  // min(max_weight, w + u) == max_weight for every u > 0
+  if (v.w != truncf(v.w) || v.w + static_cast<float>(wsum) >= 16777216.0f) return false;
+  v.w = std_min(P.max_weight, v.w + static_cast<float>(wsum));  // integer partial sums are exact
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ touched_slots, RecordView V,
                                                     u32* __restrict__ piece_front, u32* __restrict__ piece_back, u32* __restrict__ piece_wsum,
                                                     Counters* cnt) {
   const FrameParams P = *Pp;
@@ -957,7 +979,23 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
       v.w = __uint_as_float(vr.ptr[1]);
       v.c = vr.ptr[2];
     }
-    u32 max_len = run_short ? len : 0u;
+    // Most records of a frame lie in free space (saturating_update: distance stays == trunc, an integer weight is
+    // added).  A short segment that consists of such records only, on a voxel in the matching state, is folded in one
+    // step exactly like the pieces of a long segment (fold_pieces) instead of being replayed record by record; what is
+    // left to replay decides how long this wave's loop runs.
+    bool folded = false;
+    {
+      const u64 foldmask = __ballot(fold);
+      const u32 wi = fold ? static_cast<u32>(uw) : 0u;
+      const u32 psum = wave_inclusive_scan(wi);
+      const u32 seg_hi = static_cast<u32>(__shfl(static_cast<int>(psum), static_cast<int>((lane + len - 1u) & 63u), 64));
+      const bool inside = run_short && len > 0 && lane + len <= 64u;  // the whole segment lies in this wave's lanes
+      if (inside) {
+        const u64 seg = ((len == 64u) ? ~0ull : ((1ull << len) - 1ull)) << lane;
+        if ((foldmask & seg) == seg) folded = fold_pieces(P, v, seg_hi - (psum - wi));
+      }
+    }
+    u32 max_len = (run_short && !folded) ? len : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(static_cast<int>(max_len), off, 64)));
     for (u32 k = 0; k < max_len; ++k) {
@@ -976,7 +1014,7 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
           c_k = c_2;
         }
       }
-      if (run_short && k < len) update_voxel(P, v, s_k, u_k, c_k);
+      if (run_short && !folded && k < len) update_voxel(P, v, s_k, u_k, c_k);
     }
     if (run_short) {
       vr.ptr[0] = __float_as_uint(v.d);
@@ -1047,16 +1085,7 @@ __device__ __forceinline__ void replay_piece(const FrameParams& P, const RayArra
   }
   for (u32 k = 0; k < count; ++k) update_voxel(P, v, readlane_f32(s, k), readlane_f32(u, k), static_cast<u32>(__builtin_amdgcn_readlane(c, k)));
 }
-// fold a run of foldable pieces with total integer weight wsum; false when the voxel state does not allow it
-__device__ __forceinline__ bool fold_pieces(const FrameParams& P, Voxel& v, u32 wsum) {
-  if (v.d != P.trunc) return false;
-  if (v.w >= P.max_weight) return true;  // min(max_weight, w + u) == max_weight for every u > 0
-  if (v.w != truncf(v.w) || v.w + static_cast<float>(wsum) >= 16777216.0f) return false;
-  v.w = std_min(P.max_weight, v.w + static_cast<float>(wsum));  // integer partial sums are exact
-  return true;
-}
-
-__global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ touched_slots, RecordView V,
+__global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ touched_slots, RecordView V,
                                                     const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
                                                     const u32* __restrict__ piece_wsum, const Counters* cnt, u32* layer_err) {
   const FrameParams P = *Pp;
@@ -1220,6 +1249,7 @@ struct RecordSet {  // lives B1 .. B2
   u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
   u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
   u32* touched_slots = nullptr;  // [layer ht_cap]
+  int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
   SortInfo* sort_info = nullptr;
   hipEvent_t done = nullptr;  // B2 of the frame that used this set
   bool used = false;
@@ -1545,11 +1575,11 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
       hipLaunchKernelGGL(k_touch_wave<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
                          I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info);
   } else {
     hipLaunchKernelGGL(k_touch, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, F.cnt, I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info);
   }
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
   // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
@@ -1571,8 +1601,8 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
     COX_HIP(hipEventCreate(&e1));
     COX_HIP(hipEventRecord(e0, s));
   }
-  hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
-  hipLaunchKernelGGL(k_apply_long, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
+  hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
+  hipLaunchKernelGGL(k_apply_long, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
                      I->layer->d_err);
   if (timed) {
     COX_HIP(hipEventRecord(e1, s));
@@ -1859,6 +1889,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   for (RecordSet& S : I->rs) {
     ev(&S.done);
     if (st == COX_OK) st = dev_realloc(&S.touched_slots, layer->ht_cap);  // one entry per block key the table can hold
+    if (st == COX_OK) st = dev_realloc(&S.ord_info, layer->ht_cap);
     info(&S.sort_info);
   }
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
@@ -1928,7 +1959,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   }
   for (RecordSet& S : I->rs) {
     for (void* p : {static_cast<void*>(S.rec_key[0]), static_cast<void*>(S.rec_key[1]), static_cast<void*>(S.rec_ray[0]), static_cast<void*>(S.rec_ray[1]),
-                    static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots),
+                    static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots), static_cast<void*>(S.ord_info),
                     static_cast<void*>(S.sort_info)})
       ptrs.push_back(p);
     events.push_back(S.done);
