@@ -150,9 +150,12 @@ __global__ void __launch_bounds__(256) k_rays_simple(const FrameParams* __restri
 // thread = point (so neighbouring lanes are neighbouring pixels and mostly share a terminal voxel): the lanes of a
 // wave that hold the same key elect one leader, which inserts the key in the per-frame hash once and records the
 // smallest sequence number of the group as a candidate for the bundle's first visit.
-__global__ void __launch_bounds__(256) k_bundle_insert(const FrameParams* __restrict__ Pp, u64* __restrict__ fh_keys, u32* __restrict__ fh_first,
-                                                       u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
-  const FrameParams P = *Pp;
+// First kernel of a frame: with by_value the frame's parameter block arrives as a kernel argument and workgroup 0
+// stores it for the kernels that follow (saves the 4 us H2D blit per frame); captured stage graphs keep the copy.
+__global__ void __launch_bounds__(256) k_bundle_insert(FrameParams* __restrict__ Pp, FrameParams Pv, int by_value, u64* __restrict__ fh_keys,
+                                                       u32* __restrict__ fh_first, u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
+  if (by_value && blockIdx.x == 0 && threadIdx.x == 0) *Pp = Pv;
+  const FrameParams P = by_value ? Pv : *Pp;
   const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 lane = lane_id();
   bool valid = false;
@@ -1489,12 +1492,14 @@ static int stage_a1(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   BundleSet& B = *c.B;
-  COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  const bool by_value = (I->method == COX_METHOD_MERGED) && !I->use_graphs;
+  if (!by_value) COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
   COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
   if (I->method == COX_METHOD_MERGED) {
     const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
     COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
-    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, I->fh_cap - 1, B.pslot, F.cnt);
+    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
+                       B.pslot, F.cnt);
     hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
     (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I), I->sort_pts,
                                B.sort_info, s);
@@ -1746,7 +1751,6 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   if (I->method == COX_METHOD_FAST) {  // single stream, see fast_frame
     COX_TRY(fast_frame(ctx, I->st[0]));
     COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
-    COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], F.cnt, sizeof(Counters), hipMemcpyDeviceToHost, I->st[0]));
     COX_HIP(hipEventRecord(F.done, I->st[0]));
     F.used = true;
     I->last_has_counts = true;
@@ -1777,7 +1781,6 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipStreamWaitEvent(I->st[3], I->ev_b1, 0));
   }
   COX_TRY(run_stage(3, ctx));
-  COX_HIP(hipMemcpyAsync(&I->h_ring[I->frame_no % kStatRing], F.cnt, sizeof(Counters), hipMemcpyDeviceToHost, I->st[3]));
   COX_HIP(hipEventRecord(F.done, I->st[3]));
   COX_HIP(hipEventRecord(S.done, I->st[3]));
   F.used = true;
@@ -1787,9 +1790,12 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   return COX_OK;
 }
 
-static void fold_counters(cox_integrator* I) {
-  if (!I->last_has_counts) return;
-  const Counters& c = I->h_ring[I->frame_no % kStatRing];
+// the last frame's device counters are fetched when somebody asks (sync / last_stats), not once per frame: its frame
+// set is not reused before four more frames have been enqueued.  Call with all streams idle.
+static int fold_counters(cox_integrator* I) {
+  if (!I->last_has_counts) return COX_OK;
+  Counters& c = I->h_ring[I->frame_no % kStatRing];
+  COX_HIP(hipMemcpy(&c, I->fs[I->frame_no % kFrameSets].cnt, sizeof(Counters), hipMemcpyDeviceToHost));
   u64 sh[5] = {0, 0, 0, 0, 0};
   for (int s = 0; s < 64; ++s)
     for (int k = 0; k < 5; ++k) sh[k] += c.shard[s][k];
@@ -1799,6 +1805,8 @@ static void fold_counters(cox_integrator* I) {
   I->last.n_touched_voxels = sh[kShVoxels];
   I->last.n_touched_blocks = c.n_touched;
   I->last.n_new_blocks = c.n_new_blocks;
+  I->last_has_counts = false;  // folded; I->last keeps the numbers
+  return COX_OK;
 }
 
 static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc) {
@@ -1817,7 +1825,7 @@ static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, do
 // wait for all stages, fold the last frame's counters into the stats, return deferred errors
 static int integrator_finish(cox_integrator* I) {
   COX_TRY(sync_all(I));
-  fold_counters(I);
+  COX_TRY(fold_counters(I));
   // errors of every frame since the last sync are sticky in the layer's device error word; report them once
   u32 lerr = 0;
   COX_HIP(hipMemcpy(&lerr, I->layer->d_err, sizeof(u32), hipMemcpyDeviceToHost));
@@ -2028,7 +2036,7 @@ int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
   if (!I || !stats) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   COX_TRY(sync_all(I));
-  fold_counters(I);
+  COX_TRY(fold_counters(I));
   *stats = I->last;
   return COX_OK;
 }
