@@ -1,0 +1,107 @@
+"""Differential fuzzing of the HIP engine against the CPU oracle: random point clouds (not depth images), random
+rigid poses, random voxel sizes and integrator switches, several frames into one layer.  Every case must give the
+same block set, the same stats and bit-identical distance / weight / colour words.
+
+    python tests/test_gpu_fuzz.py 200          # a longer campaign (seeds 1000 ..), prints the first mismatch
+"""
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from coxgraph_amd.capi import Layer, Integrator  # noqa: E402
+from util import compare_layers, compare_stats  # noqa: E402
+
+
+def random_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    if q[0] < 0:
+        q = -q
+    t = rng.uniform(-2.0, 2.0, 3)
+    return np.concatenate([q, t]).astype(np.float32)
+
+
+def random_cloud(rng, n, max_ray):
+    kind = rng.integers(0, 4)
+    if kind == 0:    # a blob in front of the sensor
+        p = rng.normal([0, 0, 2.0], [0.8, 0.8, 0.6], (n, 3))
+    elif kind == 1:  # a plane with noise
+        u, v = rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n)
+        p = np.stack([u, v, 2.5 + 0.3 * u + rng.normal(0, 0.01, n)], axis=1)
+    elif kind == 2:  # rays of every length, many beyond max_ray (clearing rays)
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        p = d * rng.uniform(0.05, 2.0 * max_ray, (n, 1))
+    else:            # many points in few voxels (big bundles), some exactly repeated
+        c = rng.uniform(-1, 1, (8, 3)) + [0, 0, 2.0]
+        p = c[rng.integers(0, 8, n)] + rng.normal(0, 0.02, (n, 3))
+        p[::7] = p[0]
+    p = p.astype(np.float32)
+    # (non-finite points are not generated: voxblox_ros drops them before integratePointCloud, the reference's behaviour
+    #  on them is a float -> int64 cast of NaN, and the engine reports COX_ERR_INDEX_RANGE instead; see test_gpu_fusion.py)
+    if rng.random() < 0.2:   # axis-aligned rays (the DDA's -inf / NaN quirk)
+        p[rng.integers(0, n, 16)] *= np.array([0, 0, 1], np.float32)
+    rgba = rng.integers(0, 256, (n, 4)).astype(np.uint8)
+    return p, rgba
+
+
+def run_case(seed, hip, oracle):
+    rng = np.random.default_rng(seed)
+    voxel = float(rng.choice([0.03, 0.05, 0.08, 0.1, 0.2]))
+    method = str(rng.choice(["merged", "simple", "fast"]))
+    max_ray = float(rng.choice([1.5, 3.0, 5.0]))
+    ov = dict(default_truncation_distance=float(rng.choice([2, 3, 4])) * voxel, min_ray_length_m=float(rng.choice([0.05, 0.2, 0.5])),
+              max_ray_length_m=max_ray, use_const_weight=int(rng.integers(0, 2)), allow_clear=int(rng.integers(0, 2)),
+              voxel_carving_enabled=int(rng.integers(0, 2)), use_weight_dropoff=int(rng.integers(0, 2)),
+              use_sparsity_compensation_factor=int(rng.integers(0, 2)), sparsity_compensation_factor=float(rng.choice([1.0, 10.0])),
+              max_weight=float(rng.choice([50.0, 10000.0])), enable_anti_grazing=int(rng.integers(0, 2)), integrator_threads=1,
+              max_consecutive_ray_collisions=int(rng.integers(0, 5)), clear_checks_every_n_frames=int(rng.integers(1, 4)),
+              start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 3.0])))
+    frames = []
+    for _ in range(int(rng.integers(2, 6))):
+        n = int(rng.choice([1, 63, 64, 65, 700, 1024, 1025, 5000, 20000]))
+        frames.append((random_pose(rng), *random_cloud(rng, n, max_ray), bool(rng.random() < 0.15)))
+    out = []
+    for eng in (hip, oracle):
+        layer = Layer(eng, voxel, capacity_blocks=60000)
+        integ = Integrator(eng, layer, eng.default_config(**ov), method)
+        stats = []
+        for T, p, c, freespace in frames:
+            integ.integrate_points(T, p, c if seed % 5 else None, freespace=freespace)
+            stats.append(integ.last_stats())
+        out.append((layer, stats))
+    (la, sa), (lb, sb) = out
+    what = dict(seed=seed, voxel=voxel, method=method, cfg=ov, frames=[len(f[1]) for f in frames])
+    try:
+        compare_stats(sa, sb, keys=("n_points", "n_valid", "n_rays", "n_updates", "n_new_blocks"))
+        rep = compare_layers(la, lb)
+        assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+    except AssertionError as e:
+        raise AssertionError(f"{what}: {e}") from e
+    return what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_random_cases_match_the_oracle_bit_for_bit(hip, oracle, seed):
+    run_case(seed, hip, oracle)
+
+
+if __name__ == "__main__":
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import torch
+    torch.zeros(1, device="cuda")
+    import coxgraph_amd
+    from coxgraph_amd.capi import Engine
+    hip_e = coxgraph_amd.load_engine()
+    ora = Engine(os.path.join(ROOT, "oracle", "libcoxoracle.so"), "coxo_")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    for s in range(1000, 1000 + n):
+        w = run_case(s, hip_e, ora)
+        if s % 10 == 0:
+            print("ok", s, w["method"], w["voxel"], w["frames"], flush=True)
+    print("all", n, "cases identical")
