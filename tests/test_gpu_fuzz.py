@@ -9,7 +9,12 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+for _p in (_HERE, os.path.dirname(_HERE)):  # also runnable as a script: tests/ for util, the repository root for the package
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 from coxgraph_amd.capi import Layer, Integrator  # noqa: E402
 from util import compare_layers, compare_stats  # noqa: E402
 
@@ -90,9 +95,7 @@ def test_random_cases_match_the_oracle_bit_for_bit(hip, oracle, seed):
 
 
 if __name__ == "__main__":
-    import os
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, ROOT)
+    ROOT = os.path.dirname(_HERE)
     import torch
     torch.zeros(1, device="cuda")
     import coxgraph_amd
