@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--method", default="merged", choices=["merged", "simple", "fast"])
     ap.add_argument("--no-events", action="store_true", help="no HIP-event kernel timing inside the timed region")
-    ap.add_argument("--fast-frames", type=int, default=100, help="frames of the same stream also run through method 'fast' (0 = skip)")
+    ap.add_argument("--fast-frames", type=int, default=300, help="frames of the same stream also run through method 'fast' (0 = skip)")
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the CPU baseline sample (0 = skip); ~10 s of CPU work at the default")
     ap.add_argument("--reg-iters", type=int, default=50)
@@ -295,16 +295,15 @@ def main():
     # ---- the reference's configured method (`method: "fast"`, tsdf_server_euroc.yaml:6) on the same stream, for context ----
     other = None
     if rank == 0 and world == 1 and args.method != "fast" and args.fast_frames > 0:
-        nf = min(args.fast_frames, n_frames)
+        nf = min(args.fast_frames, args.steps)  # the same frames as the headline number: warm-up frames first, untimed
         layer3 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
         integ3 = Integrator(eng, layer3, cfg, "fast")
-        for i in range(min(5, nf)):
+        for i in range(args.warmup):
             T, xyz, rgba, n = dev_frames[i]
             integ3.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
         integ3.sync()
-        layer3.clear()
         t3 = time.perf_counter()
-        for i in range(nf):
+        for i in range(args.warmup, args.warmup + nf):
             T, xyz, rgba, n = dev_frames[i]
             integ3.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
         integ3.sync()

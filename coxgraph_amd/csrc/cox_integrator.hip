@@ -1267,6 +1267,7 @@ struct FastState {
   u32* reach[2] = {nullptr, nullptr};
   u32* d_changed = nullptr;  // [kFastMaxSweeps]
   u32* h_changed = nullptr;  // pinned mirror
+  hipEvent_t ev[2] = {nullptr, nullptr};  // "this batch's flags have reached the host"
   u64 off_start = 0, off_obs = 0;  // ApproxHashSet::offset_
   int reset_counter = 0;
   uint64_t sweeps_total = 0, frames = 0;
@@ -1694,9 +1695,10 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   const FastVisits V{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
   // Jacobi sweeps until one changes nothing.  (Capturing a batch into a HIP graph was measured: no gain, the sweeps are
   // bound by their own dependent loads, not by launches.)
-  // sweeps between two looks at the "changed" flags: measured on the benchmark stream (frames/s): 14+4: 1275, 8+2: 1503,
-  // 4+2: 1601, 2+1: 1564 -- most frames settle within a handful of sweeps, the first frames of a stream need 14-18
-  constexpr int kFirstBatch = 4, kNextBatch = 2;
+  // sweeps between two looks at the "changed" flags.  Most frames settle within a handful of sweeps, the first frames of a
+  // stream need 14-18.  Measured on the benchmark stream (frames/s) with a blocking look per batch: 14+4: 1275, 8+2: 1503,
+  // 4+2: 1601, 2+1: 1564; with the look one batch behind (below): 4+2: 2317, 3+1: 2408, 4+1: 2525, 6+3: 2044
+  constexpr int kFirstBatch = 4, kNextBatch = 1;
   auto enqueue = [&](int first, int count) -> int {
     for (int k = first; k < first + count; ++k) {
       hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
@@ -1706,19 +1708,26 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
     COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
     return COX_OK;
   };
-  int sweep = 0;
-  bool converged = false;
-  while (!converged) {
-    const int batch = (sweep == 0) ? kFirstBatch : kNextBatch;
-    if (sweep + batch > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
-    COX_TRY(enqueue(sweep, batch));
-    sweep += batch;
-    COX_HIP(hipStreamSynchronize(s));
-    converged = X.h_changed[sweep - 1] == 0;
+  // The host looks at the "changed" flags one batch behind what it has enqueued: the next batch is already queued while it
+  // waits for the previous one's flags, so the GPU never idles for the round trip.  Sweeps that run after convergence
+  // reproduce the fixed point, so the (at most kNextBatch) speculative sweeps cost time but cannot change the result.
+  int sweep = 0;  // sweeps enqueued
+  if (kFirstBatch + kNextBatch > kFastMaxSweeps) return COX_ERR_INTERNAL;
+  COX_TRY(enqueue(0, kFirstBatch));
+  COX_HIP(hipEventRecord(X.ev[0], s));
+  sweep = kFirstBatch;
+  for (int k = 0;; ++k) {
+    const int checked_last = sweep - 1;  // last sweep of the batch whose flags event k carries
+    if (sweep + kNextBatch > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
+    COX_TRY(enqueue(sweep, kNextBatch));
+    COX_HIP(hipEventRecord(X.ev[(k + 1) & 1], s));
+    sweep += kNextBatch;
+    COX_HIP(hipEventSynchronize(X.ev[k & 1]));
+    if (X.h_changed[checked_last] == 0) break;
   }
   X.sweeps_total += static_cast<uint64_t>(sweep);
   X.frames += 1;
-  // the last sweep changed nothing: reach[sweep & 1] == reach[(sweep - 1) & 1], and eloc / tmax belong to it
+  // the last enqueued sweep changed nothing: reach[sweep & 1] == reach[(sweep - 1) & 1], and eloc / tmax belong to it
   const u32* reach = X.reach[sweep & 1];
   hipLaunchKernelGGL(k_fast_obs_commit, gv, dim3(256), 0, s, V, reach, X.eloc, X.tmax, X.table_obs, F.cnt, vcap);
   hipLaunchKernelGGL(k_fast_finish, gr, dim3(256), 0, s, F.rays, reach, F.cnt);
@@ -1914,6 +1923,8 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
       st = COX_ERR_NO_DEVICE;
     if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&X.h_changed), sizeof(u32) * kFastMaxSweeps, hipHostMallocDefault) != hipSuccess)
       st = COX_ERR_OUT_OF_MEMORY;
+    ev(&X.ev[0]);
+    ev(&X.ev[1]);
   }
   if (st == COX_OK) {
     memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
@@ -1948,6 +1959,8 @@ void cox_integrator_destroy(cox_integrator_t* I) {
                     static_cast<void*>(X.d_changed)})
       ptrs.push_back(q);
     if (X.h_changed) (void)hipHostFree(X.h_changed);
+    for (hipEvent_t e : X.ev)
+      if (e) (void)hipEventDestroy(e);
   }
   std::vector<hipEvent_t> events = {I->ev_a1, I->ev_a2, I->ev_b1};
   for (FrameSet& F : I->fs) {
