@@ -155,6 +155,7 @@ def main():
     # are run again, one in flight, on a fresh layer; that pass also gives the kernels' undisturbed durations.
     roofline = None
     stats_sum = dict(n_valid=0, n_touched_voxels=0, n_updates=0, n_rays=0)
+    stats_max = dict(max_bundle_points=0, max_voxel_updates=0)
     if rank == 0 and not args.no_profile_pass:
         layer2 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
         integ2 = Integrator(eng, layer2, cfg, args.method)
@@ -167,6 +168,8 @@ def main():
                 st = integ2.last_stats()
                 for k in stats_sum:
                     stats_sum[k] += st[k]
+                for k in stats_max:
+                    stats_max[k] = max(stats_max[k], st[k])
             elif i == args.warmup - 1:
                 integ2.stage_times(reset=True)
         serial = integ2.stage_times()
@@ -332,6 +335,8 @@ def main():
                                    f"{args.method} integrator semantics (bit-exact vs CPU oracle), points resident in HBM",
                        "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
             "frame_stats_mean": {k: v / max(args.steps, 1) for k, v in stats_sum.items()},
+            "critical_path": dict(stats_max, note="longest sequential chains of any timed frame: points of the largest bundle (k_bundle_merge), "
+                                                  "updates of the busiest voxel (k_apply_*; free-space runs fold)"),
             "roofline": roofline, "cpu_baseline": cpu, "registration": reg, "distributed_registration": dist_reg, "other_methods": other,
         }
         print(json.dumps(line))

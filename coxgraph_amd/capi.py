@@ -42,7 +42,7 @@ class TsdfConfig(C.Structure):
 
 class FrameStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_points", "n_valid", "n_rays", "n_updates", "n_touched_voxels",
-                                          "n_touched_blocks", "n_new_blocks")]
+                                          "n_touched_blocks", "n_new_blocks", "max_bundle_points", "max_voxel_updates")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

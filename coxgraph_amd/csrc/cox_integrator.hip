@@ -51,7 +51,7 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   // [s][0] valid points, [s][1] updates, [s][2] voxels, [s][3] long runs, [s][4] rays
   u32 shard[64][16];
 };
-enum : u32 { kShValid = 0, kShUpdates = 1, kShVoxels = 2, kShLong = 3, kShRays = 4 };
+enum : u32 { kShValid = 0, kShUpdates = 1, kShVoxels = 2, kShLong = 3, kShRays = 4, kShMaxBundle = 5, kShMaxRun = 6 };  // 5, 6: maxima, not sums
 
 struct LayerView {
   u32* voxels;
@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
     const u32 begin = uniform_u32(bstart[m]);
     const u32 end = uniform_u32((m + 1 < n_bundles) ? bstart[m + 1] : n_valid);
     const bool clearing = uniform_u32(skey[begin]) >= np2;
+    if (!colour_wave && lane == 0) atomicMax(&cnt->shard[m & 63u][kShMaxBundle], end - begin);
     if (colour_wave && rgba == nullptr) {  // no colours: Color() stays (0,0,0,0)
       if (lane == 0) R.color[m] = 0u;
       continue;
@@ -894,11 +895,12 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
                                                     u32* __restrict__ piece_front, u32* __restrict__ piece_back, u32* __restrict__ piece_wsum,
                                                     Counters* cnt) {
   const FrameParams P = *Pp;
-  __shared__ u32 blk_updates, blk_voxels, blk_long;
+  __shared__ u32 blk_updates, blk_voxels, blk_long, blk_maxrun;
   if (threadIdx.x == 0) {
     blk_updates = 0;
     blk_voxels = 0;
     blk_long = 0;
+    blk_maxrun = 0;
   }
   __syncthreads();
   const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
@@ -908,7 +910,7 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
   const u32 lane = lane_id();
   const u32 n_waves = (n + 63) >> 6;
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  u32 my_updates = 0, my_voxels = 0, my_long = 0;
+  u32 my_updates = 0, my_voxels = 0, my_long = 0, my_maxrun = 0;
   for (u32 wv = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wv < n_waves; wv += waves_total) {
     const u32 wave_base = wv << 6;
     const u32 i = wave_base + lane;
@@ -998,6 +1000,12 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
         if ((foldmask & seg) == seg) folded = fold_pieces(P, v, seg_hi - (psum - wi));
       }
     }
+    {  // longest run of updates on one voxel (statistics only; long runs report theirs from k_apply_long)
+      u32 mr = (head && !is_long) ? len : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mr = max(mr, static_cast<u32>(__shfl_xor(static_cast<int>(mr), off, 64)));
+      my_maxrun = max(my_maxrun, mr);
+    }
     u32 max_len = (run_short && !folded) ? len : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(static_cast<int>(max_len), off, 64)));
@@ -1064,6 +1072,7 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
     if (my_updates) atomicAdd(&blk_updates, my_updates);
     if (my_voxels) atomicAdd(&blk_voxels, my_voxels);
     if (my_long) atomicAdd(&blk_long, my_long);
+    if (my_maxrun) atomicMax(&blk_maxrun, my_maxrun);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1071,6 +1080,7 @@ __global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restric
     if (blk_updates) atomicAdd(&sh[kShUpdates], blk_updates);
     if (blk_voxels) atomicAdd(&sh[kShVoxels], blk_voxels);
     if (blk_long) atomicAdd(&sh[kShLong], blk_long);
+    if (blk_maxrun) atomicMax(&sh[kShMaxRun], blk_maxrun);
   }
 }
 
@@ -1090,7 +1100,7 @@ __device__ __forceinline__ void replay_piece(const FrameParams& P, const RayArra
 }
 __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ touched_slots, RecordView V,
                                                     const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
-                                                    const u32* __restrict__ piece_wsum, const Counters* cnt, u32* layer_err) {
+                                                    const u32* __restrict__ piece_wsum, Counters* cnt, u32* layer_err) {
   const FrameParams P = *Pp;
   // last kernel of the frame: make this frame's error bits sticky until the host next looks
   if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
@@ -1117,6 +1127,7 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
       if (!((pb & kPieceFoldable) && fold_pieces(P, v, uniform_u32(piece_wsum[2 * w0 + 1])))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count0, lane, v);
       // front pieces of the following waves; the segment ends with the first piece shorter than 64
       bool more = true;
+      u32 seg_records = count0;  // statistics: length of this voxel's run
       for (u32 wbase = w0 + 1; more && wbase < n_waves; wbase += 64) {
         const u32 w = wbase + lane;
         const u32 pf = (w < n_waves) ? piece_front[w] : 0u;
@@ -1125,6 +1136,12 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
         const u64 end_mask = __ballot(count < 64u);
         const u32 n_use = end_mask ? static_cast<u32>(__ffsll(static_cast<long long>(end_mask))) : 64u;  // pieces [0, n_use) belong to the segment
         if (end_mask) more = false;
+        {
+          u32 c = (lane < n_use) ? count : 0u;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) c += static_cast<u32>(__shfl_xor(static_cast<int>(c), off, 64));
+          seg_records += c;
+        }
         const u64 use_mask = (n_use == 64) ? ~0ull : ((1ull << n_use) - 1ull);
         const u64 hard_mask = __ballot(!(pf & kPieceFoldable)) & use_mask;  // pieces that need a record-by-record replay
         u32 pos = 0;
@@ -1150,6 +1167,7 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
         vr.ptr[0] = __float_as_uint(v.d);
         vr.ptr[1] = __float_as_uint(v.w);
         vr.ptr[2] = v.c;
+        atomicMax(&cnt->shard[w0 & 63u][kShMaxRun], seg_records);
       }
     }
   }
@@ -1806,8 +1824,14 @@ static int fold_counters(cox_integrator* I) {
   Counters& c = I->h_ring[I->frame_no % kStatRing];
   COX_HIP(hipMemcpy(&c, I->fs[I->frame_no % kFrameSets].cnt, sizeof(Counters), hipMemcpyDeviceToHost));
   u64 sh[5] = {0, 0, 0, 0, 0};
-  for (int s = 0; s < 64; ++s)
+  u32 max_bundle = 0, max_run = 0;
+  for (int s = 0; s < 64; ++s) {
     for (int k = 0; k < 5; ++k) sh[k] += c.shard[s][k];
+    max_bundle = std::max(max_bundle, c.shard[s][kShMaxBundle]);
+    max_run = std::max(max_run, c.shard[s][kShMaxRun]);
+  }
+  I->last.max_bundle_points = max_bundle;
+  I->last.max_voxel_updates = max_run;
   I->last.n_valid = sh[kShValid];
   I->last.n_rays = (I->method == COX_METHOD_SIMPLE) ? sh[kShRays] : c.n_rays;
   I->last.n_updates = sh[kShUpdates];

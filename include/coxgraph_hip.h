@@ -90,6 +90,8 @@ typedef struct cox_frame_stats {
   uint64_t n_touched_voxels; /* distinct voxels updated */
   uint64_t n_touched_blocks; /* distinct blocks visited */
   uint64_t n_new_blocks;     /* blocks allocated by this frame */
+  uint64_t max_bundle_points;  /* merged: points of the largest bundle (length of the longest sequential mean); else 0 */
+  uint64_t max_voxel_updates;  /* most updates any one voxel received (length of the longest in-order replay) */
 } cox_frame_stats;
 
 void cox_tsdf_config_default(cox_tsdf_config* cfg);

@@ -300,6 +300,7 @@ struct TsdfConfig {
 
 struct FrameStats {
   uint64_t n_points = 0, n_valid = 0, n_rays = 0, n_updates = 0, n_touched_voxels = 0, n_touched_blocks = 0, n_new_blocks = 0;
+  uint64_t max_bundle_points = 0, max_voxel_updates = 0;
 };
 
 // voxblox MixedThreadSafeIndex::getNextIndexImpl (step_size_ = 1024, number_of_groups_ = N / 1024)
@@ -358,6 +359,7 @@ class Integrator {
     updateLayerWithStoredBlocks();
     stats_.n_new_blocks = layer_->numBlocks() - blocks_before;
     stats_.n_touched_voxels = touched_.size();
+    for (const auto& kv : touched_) stats_.max_voxel_updates = std::max<uint64_t>(stats_.max_voxel_updates, kv.second);
     last_stats = stats_;
   }
 
@@ -606,6 +608,8 @@ class Integrator {
       }
     }
     stats_.n_rays = voxel_bundles.size() + clear_bundles.size();
+    for (const auto* vec : {&voxel_bundles, &clear_bundles})
+      for (const Bundle& b : *vec) stats_.max_bundle_points = std::max<uint64_t>(stats_.max_bundle_points, b.pts.size());
     // integrateRays(non-clearing) then integrateRays(clearing)
     for (int pass = 0; pass < 2; ++pass) {
       const bool clearing = (pass == 1);

@@ -174,6 +174,8 @@ int coxo_integrator_last_stats(coxo_integrator* h, cox_frame_stats* s) {
   s->n_touched_voxels = f.n_touched_voxels;
   s->n_touched_blocks = 0;
   s->n_new_blocks = f.n_new_blocks;
+  s->max_bundle_points = f.max_bundle_points;
+  s->max_voxel_updates = f.max_voxel_updates;
   return COX_OK;
 }
 

@@ -46,7 +46,7 @@ def compare_layers(la, lb, tol=TOL, check_color=True):
     return rep
 
 
-def compare_stats(sa, sb, keys=("n_points", "n_valid", "n_rays", "n_updates", "n_touched_voxels", "n_new_blocks")):
+def compare_stats(sa, sb, keys=("n_points", "n_valid", "n_rays", "n_updates", "n_touched_voxels", "n_new_blocks", "max_bundle_points", "max_voxel_updates")):
     for a, b in zip(sa, sb):
         for k in keys:
             assert a[k] == b[k], (k, a[k], b[k])
