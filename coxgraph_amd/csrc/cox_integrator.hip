@@ -728,10 +728,15 @@ __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restric
           skip = grazing_skip(P, fh_keys, fh_mask, clearing, own_key, x, y, z);
           bkey = pack_key(x >> 4, y >> 4, z >> 4);
         }
-        u64 prev = __shfl_up(bkey, 1, 64);
-        if (lane == 0) prev = carry;
+        // a voxel touches its block unless the previous voxel THAT WAS NOT SKIPPED lies in the same block (a block whose
+        // first voxel on the ray is skipped by anti-grazing must still be allocated by the next one; found by the fuzzer)
+        const u64 kept = __ballot(act && !skip);
+        const u64 kept_below = kept & ((1ull << lane) - 1ull);
+        const int src = kept_below ? (63 - __clzll(static_cast<long long>(kept_below))) : 0;
+        const u64 prev_kept = __shfl(bkey, src, 64);
+        const u64 prev = kept_below ? prev_kept : carry;
         if (act && !skip && bkey != prev) touch_block(P, L, bkey, touched_slots, cnt, layer_err);
-        carry = __shfl(bkey, 63, 64);
+        if (kept) carry = __shfl(bkey, 63 - __clzll(static_cast<long long>(kept)), 64);
       }
       wave_lds_handover();  // the next ray of this wave reuses the LDS scratch
     } else if (lane == 0) {
@@ -1454,6 +1459,8 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   }
   I->rcap = rcap;
   I->pcap = cap;
+  // hipMemset runs on the legacy default stream, which the engine's non-blocking streams do not wait for
+  COX_HIP(hipDeviceSynchronize());
   return COX_OK;
 }
 
@@ -1862,7 +1869,10 @@ static int integrator_finish(cox_integrator* I) {
   // errors of every frame since the last sync are sticky in the layer's device error word; report them once
   u32 lerr = 0;
   COX_HIP(hipMemcpy(&lerr, I->layer->d_err, sizeof(u32), hipMemcpyDeviceToHost));
-  if (lerr) COX_HIP(hipMemset(I->layer->d_err, 0, sizeof(u32)));
+  if (lerr) {
+    COX_HIP(hipMemset(I->layer->d_err, 0, sizeof(u32)));
+    COX_HIP(hipDeviceSynchronize());  // default-stream memset: the engine's streams would not wait for it
+  }
   drain_events(I->apply_events, &I->apply_ms, &I->apply_launches);
   drain_events(I->merge_events, &I->merge_ms, &I->merge_launches);
   return err_bits_to_status(lerr);
@@ -1955,6 +1965,9 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     memset(I->h_params, 0, sizeof(FrameParams) * kFrameSets);
     st = ensure_capacity(I, 640 * 480);
   }
+  // the initialising hipMemsets above ran on the legacy default stream; the engine's streams are non-blocking and do not
+  // wait for it (found by the fuzz campaign: a table read before it had been cleared, once in 1 500 cases)
+  if (st == COX_OK && hipDeviceSynchronize() != hipSuccess) st = COX_ERR_NO_DEVICE;
   if (st != COX_OK) {
     cox_integrator_destroy(I);
     return st;

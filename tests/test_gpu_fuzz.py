@@ -89,7 +89,9 @@ def run_case(seed, hip, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+# 3395: merged + anti-grazing + no carving: the first voxel of a ray inside a new block is skipped by anti-grazing, the
+# block must still be allocated by the next voxel (k_touch_wave once missed it; found by the campaign below)
+@pytest.mark.parametrize("seed", list(range(24)) + [3395])
 def test_random_cases_match_the_oracle_bit_for_bit(hip, oracle, seed):
     run_case(seed, hip, oracle)
 
@@ -103,7 +105,8 @@ if __name__ == "__main__":
     hip_e = coxgraph_amd.load_engine()
     ora = Engine(os.path.join(ROOT, "oracle", "libcoxoracle.so"), "coxo_")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    for s in range(1000, 1000 + n):
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    for s in range(first, first + n):
         w = run_case(s, hip_e, ora)
         if s % 10 == 0:
             print("ok", s, w["method"], w["voxel"], w["frames"], flush=True)
