@@ -2,7 +2,7 @@
 rigid poses, random voxel sizes and integrator switches, several frames into one layer.  Every case must give the
 same block set, the same stats and bit-identical distance / weight / colour words.
 
-    python tests/test_gpu_fuzz.py 200          # a longer campaign (seeds 1000 ..), prints the first mismatch
+    python tests/test_gpu_fuzz.py 200 [first_seed [heavy]]   # a longer campaign, stops at the first mismatch
 """
 import sys
 
@@ -52,11 +52,17 @@ def random_cloud(rng, n, max_ray):
     return p, rgba
 
 
-def run_case(seed, hip, oracle):
+def run_case(seed, hip, oracle, heavy=False):
     rng = np.random.default_rng(seed)
     voxel = float(rng.choice([0.03, 0.05, 0.08, 0.1, 0.2]))
     method = str(rng.choice(["merged", "simple", "fast"]))
     max_ray = float(rng.choice([1.5, 3.0, 5.0]))
+    sizes = [1, 63, 64, 65, 700, 1024, 1025, 5000, 20000]
+    if heavy:  # long rays (the 512-plane DDA instantiation and its sequential fallback), fine voxels, big clouds
+        voxel = float(rng.choice([0.02, 0.03, 0.04]))
+        max_ray = float(rng.choice([4.0, 6.0, 9.0]))
+        method = str(rng.choice(["merged", "merged", "fast", "simple"]))
+        sizes = [3000, 20000, 60000] if method != "simple" else [500, 3000]
     ov = dict(default_truncation_distance=float(rng.choice([2, 3, 4])) * voxel, min_ray_length_m=float(rng.choice([0.05, 0.2, 0.5])),
               max_ray_length_m=max_ray, use_const_weight=int(rng.integers(0, 2)), allow_clear=int(rng.integers(0, 2)),
               voxel_carving_enabled=int(rng.integers(0, 2)), use_weight_dropoff=int(rng.integers(0, 2)),
@@ -66,11 +72,11 @@ def run_case(seed, hip, oracle):
               start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 3.0])))
     frames = []
     for _ in range(int(rng.integers(2, 6))):
-        n = int(rng.choice([1, 63, 64, 65, 700, 1024, 1025, 5000, 20000]))
+        n = int(rng.choice(sizes))
         frames.append((random_pose(rng), *random_cloud(rng, n, max_ray), bool(rng.random() < 0.15)))
     out = []
     for eng in (hip, oracle):
-        layer = Layer(eng, voxel, capacity_blocks=60000)
+        layer = Layer(eng, voxel, capacity_blocks=250000 if heavy else 60000)
         integ = Integrator(eng, layer, eng.default_config(**ov), method)
         stats = []
         for T, p, c, freespace in frames:
@@ -106,8 +112,9 @@ if __name__ == "__main__":
     ora = Engine(os.path.join(ROOT, "oracle", "libcoxoracle.so"), "coxo_")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    heavy = len(sys.argv) > 3 and sys.argv[3] == "heavy"
     for s in range(first, first + n):
-        w = run_case(s, hip_e, ora)
+        w = run_case(s, hip_e, ora, heavy)
         if s % 10 == 0:
             print("ok", s, w["method"], w["voxel"], w["frames"], flush=True)
     print("all", n, "cases identical")

@@ -1,6 +1,8 @@
 """Differential fuzzing of the paths around the integrator: recover-mode clouds, layer merge / rigid resample,
 registration cost.  HIP engine vs CPU oracle, same random inputs, bit-identical results (registration: the documented
 tolerances, in practice identical as well)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from coxgraph_amd.capi import MeshMsg, MeshConverter, Layer, Integrator, RegPoin
 from util import run_frames, compare_layers
 
 pytestmark = pytest.mark.gpu
+MORE = int(os.environ.get("COX_FUZZ_SEEDS", "0"))  # COX_FUZZ_SEEDS=500 python -m pytest tests/test_gpu_fuzz_aux.py -m gpu: a campaign
 
 
 def random_pose7(rng, scale=2.0):
@@ -44,7 +47,7 @@ def random_mesh(rng):
     return MeshMsg(np.float32(edge), blocks, traj)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(max(16, MORE)))
 def test_recover_clouds_fuzz(hip, oracle, seed):
     rng = np.random.default_rng(500 + seed)
     msg = random_mesh(rng)
@@ -70,7 +73,7 @@ def two_layers(oracle):
     return la.download(), lb.download()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(max(8, MORE // 4)))
 def test_layer_merge_fuzz(hip, oracle, two_layers, seed):
     rng = np.random.default_rng(700 + seed)
     (ia, va), (ib, vb) = two_layers
@@ -90,7 +93,7 @@ def test_layer_merge_fuzz(hip, oracle, two_layers, seed):
     assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(max(8, MORE // 2)))
 def test_registration_fuzz(hip, oracle, two_layers, seed):
     (ia, va), (ib, vb) = two_layers
     rng = np.random.default_rng(900 + seed)
