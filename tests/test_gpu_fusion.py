@@ -330,3 +330,59 @@ def test_layer_merge_matches_oracle(hip, oracle):
         rep = compare_layers(out["hip"][k], out["oracle"][k], tol=1e-6)
         print(what, rep)
         assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, (what, rep)
+
+
+@pytest.mark.parametrize("method,sub", [("merged", 1), ("merged", 5), ("fast", 1), ("simple", 11)])
+def test_async_device_path_equals_the_synchronous_one(hip, method, sub):
+    """bench.py's path: frames resident on the GPU, enqueued back to back without waiting (several frames in flight on
+    the engine's streams, buffers rotating) -- must give the layer the frame-by-frame synchronous host path gives."""
+    import torch
+    n_frames = 48
+    frames = [synth.make_frame(t) for t in range(n_frames)]
+    cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
+    a, b = Layer(hip, 0.05, capacity_blocks=16384), Layer(hip, 0.05, capacity_blocks=16384)
+    ia, ib = Integrator(hip, a, cfg, method), Integrator(hip, b, cfg, method)
+    dev = [(T, torch.from_numpy(np.ascontiguousarray(p[::sub])).cuda(), torch.from_numpy(np.ascontiguousarray(c[::sub])).cuda()) for T, p, c, _ in frames]
+    torch.cuda.synchronize()
+    for T, xyz, rgba in dev:                      # no sync between frames
+        ia.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), xyz.shape[0])
+    ia.sync()
+    for T, p, c, _ in frames:                     # host buffers, one frame at a time
+        ib.integrate_points(T, p[::sub], c[::sub])
+    assert ia.last_stats() == ib.last_stats()
+    ja, va = a.download()
+    jb, vb = b.download()
+    assert np.array_equal(ja, jb) and np.array_equal(va, vb)
+
+
+def test_async_stream_with_changing_sizes_and_a_capacity_growth(hip, oracle):
+    """Frames of very different sizes back to back, one of them larger than the integrator's initial capacity (buffers are
+    reallocated in the middle of the stream), an empty one in between; checked against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    clouds = []
+    for t in range(14):
+        T, p, c, _ = synth.make_frame(3 * t)
+        if t == 6:      # 614 400 points > 640 x 480
+            _, p2, c2, _ = synth.make_frame(3 * t + 1)
+            p, c = np.concatenate([p, p2]), np.concatenate([c, c2])
+        elif t == 9:
+            p, c = p[:0], c[:0]
+        else:
+            keep = rng.random(len(p)) < rng.choice([0.002, 0.05, 0.3, 1.0])
+            p, c = p[keep], c[keep]
+        clouds.append((T, np.ascontiguousarray(p), np.ascontiguousarray(c)))
+    cfg_kw = dict(integrator_threads=1, **synth.integrator_overrides(0.10))
+    a = Layer(hip, 0.10, capacity_blocks=8192)
+    ia = Integrator(hip, a, hip.default_config(**cfg_kw), "merged")
+    dev = [(T, torch.from_numpy(p).cuda(), torch.from_numpy(c).cuda()) for T, p, c in clouds]
+    torch.cuda.synchronize()
+    for T, xyz, rgba in dev:
+        ia.integrate_points_dev(T, xyz.data_ptr() if xyz.shape[0] else 0, rgba.data_ptr() if xyz.shape[0] else 0, xyz.shape[0])
+    ia.sync()
+    b = Layer(oracle, 0.10)
+    ib = Integrator(oracle, b, oracle.default_config(**cfg_kw), "merged")
+    for T, p, c in clouds:
+        ib.integrate_points(T, p, c)
+    rep = compare_layers(a, b)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
