@@ -386,3 +386,19 @@ def test_async_stream_with_changing_sizes_and_a_capacity_growth(hip, oracle):
         ib.integrate_points(T, p, c)
     rep = compare_layers(a, b)
     assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+def test_two_integrators_share_one_layer(hip, oracle):
+    """A client may drive one layer with more than one integrator (e.g. a merged one for the live stream and a fast one for
+    recover mode): frame ids and per-frame block ordinals live in the layer, so alternating between them stays exact."""
+    res = []
+    for eng in (hip, oracle):
+        cfg = eng.default_config(integrator_threads=1, **synth.integrator_overrides(0.10))
+        layer = Layer(eng, 0.10, capacity_blocks=8192)
+        ints = [Integrator(eng, layer, cfg, m) for m in ("merged", "fast", "simple")]
+        for t in range(9):
+            T, p, c, _ = synth.make_frame(4 * t)
+            ints[t % 3].integrate_points(T, p[::9], c[::9])
+        res.append(layer)
+    rep = compare_layers(res[0], res[1])
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
