@@ -402,3 +402,18 @@ def test_two_integrators_share_one_layer(hip, oracle):
         res.append(layer)
     rep = compare_layers(res[0], res[1])
     assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+def test_pool_exactly_full_and_one_block_short(hip, oracle):
+    """A layer created with exactly as many blocks as the frames need works and equals the oracle; with one block less
+    the engine reports COX_ERR_POOL_EXHAUSTED (never a silent partial map)."""
+    kw = dict(method="merged", voxel=0.05, frames=[0, 20, 40], subsample=3)
+    lb, _, _ = run_frames(oracle, **kw)
+    need = lb.stats()[0]
+    assert need > 50
+    la, _, _ = run_frames(hip, capacity_blocks=need, **kw)
+    rep = compare_layers(la, lb)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and la.stats()[0] == need
+    with pytest.raises(CoxError) as e:
+        run_frames(hip, capacity_blocks=need - 1, **kw)
+    assert e.value.status == -4
