@@ -19,12 +19,14 @@ from coxgraph_amd.capi import Layer, Integrator  # noqa: E402
 from util import compare_layers, compare_stats  # noqa: E402
 
 
-def random_pose(rng):
+def random_pose(rng, far=False):
     q = rng.normal(size=4)
     q /= np.linalg.norm(q)
     if q[0] < 0:
         q = -q
     t = rng.uniform(-2.0, 2.0, 3)
+    if far and rng.random() < 0.1:  # far from the origin: large voxel indices, coarse float grid
+        t = t + rng.uniform(-3000.0, 3000.0, 3)
     return np.concatenate([q, t]).astype(np.float32)
 
 
@@ -73,7 +75,7 @@ def run_case(seed, hip, oracle, heavy=False):
     frames = []
     for _ in range(int(rng.integers(2, 6))):
         n = int(rng.choice(sizes))
-        frames.append((random_pose(rng), *random_cloud(rng, n, max_ray), bool(rng.random() < 0.15)))
+        frames.append((random_pose(rng, far=seed >= 20000), *random_cloud(rng, n, max_ray), bool(rng.random() < 0.15)))  # seeds >= 20000: some poses km away
     out = []
     for eng in (hip, oracle):
         layer = Layer(eng, voxel, capacity_blocks=250000 if heavy else 60000)
