@@ -87,8 +87,11 @@ __device__ __forceinline__ u32 pack_rgba_wire(const uint8_t* rgba, u32 i) {
   const u32 v = reinterpret_cast<const u32*>(rgba)[i];  // little endian: r | g<<8 | b<<16 | a<<24
   return ((v >> 24) & 255u) | (((v >> 16) & 255u) << 8) | (((v >> 8) & 255u) << 16) | ((v & 255u) << 24);
 }
+// isPointValid.  Non-finite points (which voxblox_ros filters out before the integrator, and on which upstream's
+// float -> int64 index casts are undefined) are defined as invalid here and in the oracle.
 __device__ __forceinline__ bool point_valid(const FrameParams& P, F3 p, bool* clearing) {
   const float r = sqrtf(dot3(p, p));
+  if (!(r <= 3.0e38f)) return false;  // NaN or inf in any coordinate
   if (r < P.min_ray) return false;
   if (r > P.max_ray) {
     if (P.allow_clear || P.freespace) {

@@ -383,8 +383,11 @@ class Integrator {
 
   size_t orderIndex(size_t seq, size_t n) const { return cfg_.integration_order_mode == 0 ? mixedIndex(seq, n) : seq; }
 
+  // Non-finite points: upstream would cast NaN to an int64 voxel index (undefined); voxblox_ros drops such points before
+  // the integrator sees them.  Defined here (and in the engine) as invalid.
   bool isPointValid(V3 p, bool freespace, bool* is_clearing) const {
     const float r = norm(p);
+    if (!(r <= 3.0e38f)) return false;
     if (r < cfg_.min_ray_length_m) return false;
     if (r > cfg_.max_ray_length_m) {
       if (cfg_.allow_clear || freespace) {
