@@ -417,3 +417,48 @@ def test_pool_exactly_full_and_one_block_short(hip, oracle):
     with pytest.raises(CoxError) as e:
         run_frames(hip, capacity_blocks=need - 1, **kw)
     assert e.value.status == -4
+
+
+def test_independent_handles_from_several_host_threads(hip):
+    """Handles are not thread-safe, but different handles may be driven from different threads (several clients on one
+    GPU): three clients fused concurrently give the layers they give one after the other."""
+    import threading
+    import torch
+    cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(0.10))
+    n_clients, n_frames = 3, 24
+    streams = []
+    for k in range(n_clients):
+        fr = []
+        for t in range(n_frames):
+            T, p, c, _ = synth.make_frame(2 * t, client=k, n_clients=n_clients)
+            fr.append((T, torch.from_numpy(np.ascontiguousarray(p[::3])).cuda(), torch.from_numpy(np.ascontiguousarray(c[::3])).cuda()))
+        streams.append(fr)
+    torch.cuda.synchronize()
+
+    def fuse(frames, method):
+        layer = Layer(hip, 0.10, capacity_blocks=8192)
+        integ = Integrator(hip, layer, cfg, method)
+        for T, xyz, rgba in frames:
+            integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), xyz.shape[0])
+        integ.sync()
+        return layer.download()
+
+    methods = ["merged", "fast", "merged"]
+    alone = [fuse(streams[k], methods[k]) for k in range(n_clients)]
+    together = [None] * n_clients
+    errors = []
+
+    def work(k):
+        try:
+            together[k] = fuse(streams[k], methods[k])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(n_clients)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for (ia, va), (ib, vb) in zip(alone, together):
+        assert np.array_equal(ia, ib) and np.array_equal(va, vb)
