@@ -116,3 +116,22 @@ def test_registration_fuzz(hip, oracle, two_layers, seed):
     assert np.max(np.abs(jfa - jfb)) <= 1e-3 * max(1.0, np.max(np.abs(jfb))) and np.max(np.abs(jra - jrb)) <= 1e-3 * max(1.0, np.max(np.abs(jrb)))
     assert np.allclose(Ha, Hb, rtol=1e-6, atol=1e-6 * max(1.0, np.max(np.abs(Hb)))) and np.allclose(ba, bb, rtol=1e-6, atol=1e-6 * max(1.0, np.max(np.abs(bb))))
     assert abs(ca - cb) <= 1e-6 * max(1.0, cb)
+
+
+@pytest.mark.parametrize("seed", range(max(8, MORE // 8)))
+def test_recover_process_mesh_fuzz(hip, oracle, seed):
+    """The whole recover-mode call: random mesh -> clouds -> one integratePointCloud per pose -> layer."""
+    rng = np.random.default_rng(1100 + seed)
+    msg = random_mesh(rng)
+    step = float(rng.choice([0.05, 0.2]))
+    method = str(rng.choice(["merged", "fast", "simple"]))
+    voxel = float(rng.choice([0.05, 0.1]))
+    res = []
+    for eng in (hip, oracle):
+        cfg = eng.default_config(integrator_threads=1, default_truncation_distance=3 * voxel, max_ray_length_m=8.0, min_ray_length_m=0.05, use_const_weight=1)
+        layer = Layer(eng, voxel, capacity_blocks=60000)
+        integ = Integrator(eng, layer, cfg, method)
+        res.append((layer, MeshConverter(eng, step).process_mesh(integ, msg)))
+    assert res[0][1] == res[1][1]
+    rep = compare_layers(res[0][0], res[1][0])
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
