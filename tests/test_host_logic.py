@@ -133,3 +133,43 @@ def test_cpp_adapters_run_on_the_gpu(hip, tmp_path):
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def _build_posegraph_smoke(hip, tmp_path):
+    exe = str(tmp_path / "posegraph_smoke")
+    libdir = os.path.dirname(hip.path)
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "posegraph_smoke.cpp"),
+                           "-L" + libdir, "-lcoxgraph_hip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_pose_graph_agrees_with_the_python_one(hip, tmp_path):
+    """coxgraph_amd/host/coxgraph_hip_posegraph.hpp (the C++ host side of the server's pose graph) against
+    coxgraph_amd/posegraph.py on a 5-submap, 2-client graph with loop closures and consecutive-submap constraints
+    (no registration constraint, so no GPU is needed): same costs, same iteration counts, same poses."""
+    from coxgraph_amd.posegraph import PoseGraphInterface
+    out = subprocess.run([_build_posegraph_smoke(hip, tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    summary = [float(x) for x in lines[0].split()[1:]]
+    cpp = {int(l.split()[1]): np.array([float(x) for x in l.split()[2:]]) for l in lines[1:] if l.startswith("pose")}
+    pg = PoseGraphInterface()
+    for sid, p, c in [(0, (0, 0, 0, 0), 0), (1, (1.0, 0.1, 0.0, 0.05), 0), (2, (2.1, 0.3, 0.02, 0.12), 0), (3, (0.2, 1.9, -0.03, 1.50), 1),
+                      (4, (0.1, 3.1, 0.01, 1.62), 1)]:
+        pg.addSubmap(sid, p, c)
+    pg.updateSubmapRPConstraints()
+    pg.addLoopClosureMeasurement(0, 3, [0.15, 2.05, 0.0, 1.57])
+    pg.addLoopClosureMeasurement(2, 4, [-1.8, 2.9, 0.05, 1.49])
+    pg.addLoopClosureMeasurement(1, 2, [1.05, -0.05, 0.01, 0.02])
+    first, second = pg.optimize(False)
+    assert abs(summary[0] - second["initial_cost"]) < 1e-9 and abs(summary[1] - second["final_cost"]) < 1e-9
+    assert (int(summary[2]), int(summary[3])) == (first["iterations"], second["iterations"])
+    for sid, pose in pg.getPoseMap().items():
+        assert np.allclose(cpp[sid], pose, rtol=0, atol=1e-9), (sid, cpp[sid], pose)
+
+
+@pytest.mark.gpu
+def test_cpp_pose_graph_with_a_registration_constraint_on_the_gpu(hip, tmp_path):
+    out = subprocess.run([_build_posegraph_smoke(hip, tmp_path), "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "registration" in out.stdout
