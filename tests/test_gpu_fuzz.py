@@ -106,6 +106,13 @@ def test_random_cases_match_the_oracle_bit_for_bit(hip, oracle, seed):
     run_case(seed, hip, oracle)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [9003, 50011])
+def test_heavy_random_cases(hip, oracle, seed):
+    """long rays (512-plane DDA), 2-4 cm voxels, clouds of up to 60 000 points"""
+    run_case(seed, hip, oracle, heavy=True)
+
+
 if __name__ == "__main__":
     ROOT = os.path.dirname(_HERE)
     import torch
