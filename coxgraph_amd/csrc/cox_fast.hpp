@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) k_fast_start_commit(const FrameParams* __
 }
 // thread = sequence number: the points that start a ray, compacted in visiting order (ray id = rank among them)
 __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict__ Pp, const u32* __restrict__ fresh, const u32* __restrict__ rank, RayArrays R,
-                                                   Counters* cnt) {
+                                                   u32* __restrict__ cap, u32 cap0, Counters* cnt) {
   const FrameParams P = *Pp;
   for (u32 seq = blockIdx.x * blockDim.x + threadIdx.x; seq < P.n_points; seq += gridDim.x * blockDim.x) {
     if (!fresh[seq]) continue;
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict
     R.color[r] = pack_rgba_wire(P.rgba, idx);
     R.flags[r] = 1u | (clearing ? 2u : 0u);
     R.nsteps[r] = d.nsteps;  // the whole walk; replaced by the ray's reach once that is known
+    cap[r] = min(d.nsteps, cap0);  // candidate visits are generated for the first cap[r] steps (k_fast_grow_caps)
   }
 }
 
@@ -123,7 +124,8 @@ __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict
 // integrator's bundles, wave_ray_path; sequential on lane 0 for the rays that one does not cover)
 template <u32 kAxisCap>
 __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ vhash, u32* __restrict__ vkey,
-                                                     u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ reach, u32 vcap, Counters* cnt) {
+                                                     u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ reach, const u32* __restrict__ cap, int init_reach, u32 vcap,
+                                                     Counters* cnt) {
   const FrameParams P = *Pp;
   __shared__ float lds_t[4][3 * kAxisCap];
   __shared__ u32 lds_path[4][3 * kAxisCap];
@@ -143,14 +145,15 @@ __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restri
       }
       continue;
     }
-    const u32 ns = uniform_u32(R.nsteps[r]);
-    if (lane == 0) reach[r] = ns;
+    const u32 nfull = uniform_u32(R.nsteps[r]);
+    const u32 ns = uniform_u32(cap[r]);  // <= nfull
+    if (lane == 0 && init_reach) reach[r] = ns;
     if (ns == 0) continue;
     const u32 off = uniform_u32(R.rec_off[r]);
     const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
     Dda d;
     dda_setup(d, P, pg, (uniform_u32(R.flags[r]) & 2u) != 0);
-    if (wave_ray_path<kAxisCap>(d, ns, tl, path, lane)) {
+    if (wave_ray_path<kAxisCap>(d, nfull, tl, path, lane, ns)) {
       for (u32 s = lane; s < ns; s += 64) {
         const u32 p = path[s];
         const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];
@@ -283,7 +286,8 @@ __device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* _
 // collisions in a row" is the first lane whose run of set bits (continued from the previous 64 steps) is long enough.
 __global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collisions, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
                                                     const u32* __restrict__ tmax, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
-                                                    u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt) {
+                                                    u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt, u32 vcap) {
+  if (cnt->n_records > vcap) return;  // frame dropped (k_fast_visits): there are no visits to walk
   const u32 n_rays = cnt->n_rays;
   const u32 lane = lane_id();
   const u32 n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -335,6 +339,27 @@ __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32
     const u32 e = fast_active(V, reach, i) ? i + 1 : fast_prev_performed(V, eloc, tmax, i, key);
     if (e) table_obs[key] = V.shash[e - 1];
   }
+}
+// Candidate visits are generated for the first cap[r] steps of a ray only (most rays stop within a few steps, their walks
+// are hundreds of voxels long at fine voxel sizes).  A converged ray that reached its cap without stopping may want to go
+// on: it gets its whole walk and the round is repeated with the longer list; rays that stopped are final as far as their own
+// list goes, and the fixed point of the last round (nobody at a cap short of its whole walk) contains every performed visit,
+// so it is the sequential result.
+__global__ void __launch_bounds__(256) k_fast_grow_caps(const u32* __restrict__ nfull, u32* __restrict__ cap, u32* __restrict__ reach_a, u32* __restrict__ reach_b,
+                                                        u32* __restrict__ grew, const Counters* cnt) {
+  const u32 n_rays = cnt->n_rays;
+  bool any = false;
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
+    const u32 c = cap[r], nf = nfull[r];
+    if (c < nf && reach_a[r] >= c) {
+      const u32 nc = nf;  // a ray that got through its first steps unstopped mostly goes all the way: take the whole walk
+      cap[r] = nc;
+      reach_a[r] = nc;  // guess: it keeps going
+      reach_b[r] = nc;
+      any = true;
+    }
+  }
+  if (__ballot(any) && lane_id() == 0) atomicOr(grew, 1u);
 }
 // hand the rays over to the record pipeline: a ray emits its first reach[r] voxels
 __global__ void __launch_bounds__(256) k_fast_finish(RayArrays R, const u32* __restrict__ reach, Counters* cnt) {

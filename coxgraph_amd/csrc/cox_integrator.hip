@@ -618,12 +618,18 @@ __device__ __forceinline__ int dda_step_axis(Dda& d) {
 }
 // Fills path[0, ns) (LDS, this wave's) with the packed per-axis crossing counts of every step.  Returns false
 // when the ray needs the sequential fallback (nothing usable was written).
+// `limit`: only the first min(ns, limit) steps are wanted (the fast integrator's capped candidate lists).  Each axis then
+// needs its first limit + 1 crossings only: a crossing whose rank is below the limit is preceded by fewer than `limit`
+// crossings of any other axis, so the truncated sequences still count them exactly; everything else is discarded.
 template <u32 kAxisCap>
-__device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /*[3][kAxisCap]*/, u32* path, u32 lane) {
+__device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /*[3][kAxisCap]*/, u32* path, u32 lane, u32 limit = 0xFFFFFFFFu) {
   if (d0.sgn[0] == 0 || d0.sgn[1] == 0 || d0.sgn[2] == 0) return false;
-  const u32 g0 = d0.n_axis[0] + 2, g1 = d0.n_axis[1] + 2, g2 = d0.n_axis[2] + 2;
-  if (g0 > kAxisCap || g1 > kAxisCap || g2 > kAxisCap || ns > 3 * kAxisCap) return false;
-  const u32 L = ns - 1;
+  const u32 want = min(ns, limit);
+  const u32 gen = (want < 0xFFFFFFFEu) ? want + 1u : want;
+  const u32 f0 = d0.n_axis[0] + 2, f1 = d0.n_axis[1] + 2, f2 = d0.n_axis[2] + 2;  // whole sequences (two entries past the last crossing)
+  const u32 g0 = min(f0, gen), g1 = min(f1, gen), g2 = min(f2, gen);              // generated
+  if (g0 > kAxisCap || g1 > kAxisCap || g2 > kAxisCap || want > 3 * kAxisCap) return false;
+  const u32 L = want - 1;
   if (lane < 3) {
     // the per-axis values are picked with selects on opaque copies: left alone, the compiler turns "lane == 0 ? a[0] :
     // lane == 1 ? a[1] : a[2]" into a[lane] and moves the whole Dda into scratch memory (72 B per lane written per ray)
@@ -655,8 +661,8 @@ __device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /
       const u32 rank = c0 + c1 + c2;
       if (rank < L) {
         path[rank + 1] = pack_path(c0 + (k == 0 ? 1u : 0u), c1 + (k == 1 ? 1u : 0u), c2 + (k == 2 ? 1u : 0u));
-        const u32 g = (k == 0) ? g0 : (k == 1) ? g1 : g2;
-        if (j == g - 1) bad = true;  // the walk would go on to a crossing that was not generated
+        const u32 f = (k == 0) ? f0 : (k == 1) ? f1 : f2;
+        if (j == f - 1) bad = true;  // the walk would go on to a crossing past the ones the ray has
       }
     }
   }
@@ -1289,6 +1295,8 @@ constexpr int kFastMaxSweeps = 512;
 struct FastState {
   u64 *fhash = nullptr, *vhash = nullptr, *table_start = nullptr, *table_obs = nullptr;
   u64* shash = nullptr;
+  u32* cap = nullptr;   // candidate-visit cap per ray
+  u32 cap0 = 0xFFFFFFFFu;  // initial cap (no capping unless walks are long: set from the configuration)
   u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *sray = nullptr, *sstep = nullptr;
   u32* reach[2] = {nullptr, nullptr};
   u32* d_changed = nullptr;  // [kFastMaxSweeps]
@@ -1423,6 +1431,9 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
   I->steps_max = max_steps_per_ray(I);
   I->small_axis_cap = (I->steps_max - 1) / 3 + 2 <= kAxisCapSmall;  // steps_max = 3 * (planes per axis bound) + 1
+  // fast: cap the candidate-visit lists only where walks are long (2 cm and finer with the reference's ray lengths); at 5 cm
+  // the second round costs more than the shorter lists save
+  I->fast.cap0 = ((I->steps_max - 1) / 3 > 140) ? 32u : 0xFFFFFFFFu;
   const u64 want = static_cast<u64>(cap) * I->steps_max;
   const u64 limit = 0x7FFFFFF0ull;
   const u32 rcap = static_cast<u32>(std::min(want, limit));
@@ -1442,6 +1453,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&X.fhash, cap));
     COX_TRY(dev_realloc(&X.fresh, cap));
     COX_TRY(dev_realloc(&X.rank, cap));
+    COX_TRY(dev_realloc(&X.cap, cap));
     COX_TRY(dev_realloc(&X.reach[0], cap));
     COX_TRY(dev_realloc(&X.reach[1], cap));
     COX_TRY(dev_realloc(&X.vhash, rcap));
@@ -1710,48 +1722,62 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   hipLaunchKernelGGL(k_fast_start_flags, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start, X.fresh);
   hipLaunchKernelGGL(k_fast_start_commit, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start);
   exclusive_scan_u32(X.fresh, X.rank, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
-  hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, F.cnt);
-  // candidate visits: every voxel of every ray's whole walk, sorted by slot of the observed set
-  exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
-  if (I->small_axis_cap)
-    hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
-  else
-    hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[0], vcap, F.cnt);
-  const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21), kFastSlotBits,
-                                      false, 2, I->sort_rec, nullptr, s);
-  hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
-  const FastVisits V{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
+  hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, X.cap, X.cap0, F.cnt);
   // Jacobi sweeps until one changes nothing.  (Capturing a batch into a HIP graph was measured: no gain, the sweeps are
   // bound by their own dependent loads, not by launches.)
   // sweeps between two looks at the "changed" flags.  Most frames settle within a handful of sweeps, the first frames of a
   // stream need 14-18.  Measured on the benchmark stream (frames/s) with a blocking look per batch: 14+4: 1275, 8+2: 1503,
   // 4+2: 1601, 2+1: 1564; with the look one batch behind (below): 4+2: 2317, 3+1: 2408, 4+1: 2525, 6+3: 2044
   constexpr int kFirstBatch = 4, kNextBatch = 1;
-  auto enqueue = [&](int first, int count) -> int {
-    for (int k = first; k < first + count; ++k) {
-      hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
-      hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, F.rays.nsteps, X.eloc, X.tmax, X.table_obs,
-                         X.reach[k & 1], X.reach[(k + 1) & 1], X.d_changed + k, F.cnt);
+  int sweep = 0;  // sweeps enqueued (over all rounds)
+  FastVisits V{};
+  for (int round = 0;; ++round) {
+    // candidate visits: the first cap[r] voxels of every ray's walk, sorted by slot of the observed set
+    exclusive_scan_u32(X.cap, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
+    if (I->small_axis_cap)
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
+                         X.cap, round == 0 ? 1 : 0, vcap, F.cnt);
+    else
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
+                         X.cap, round == 0 ? 1 : 0, vcap, F.cnt);
+    const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21),
+                                        kFastSlotBits, false, 2, I->sort_rec, nullptr, s);
+    hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
+    V = FastVisits{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
+    auto enqueue = [&](int first, int count) -> int {
+      for (int k = first; k < first + count; ++k) {
+        hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
+        hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, X.cap, X.eloc, X.tmax, X.table_obs, X.reach[k & 1],
+                           X.reach[(k + 1) & 1], X.d_changed + k, F.cnt, vcap);
+      }
+      COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
+      return COX_OK;
+    };
+    // The host looks at the "changed" flags one batch behind what it has enqueued: the next batch is already queued while it
+    // waits for the previous one's flags, so the GPU never idles for the round trip.  Sweeps that run after convergence
+    // reproduce the fixed point, so the (at most kNextBatch) speculative sweeps cost time but cannot change the result.
+    const int first_batch = (round == 0) ? kFirstBatch : 1;  // later rounds start from the previous round's fixed point
+    if (sweep + first_batch + kNextBatch + 1 > kFastMaxSweeps) return COX_ERR_INTERNAL;
+    COX_TRY(enqueue(sweep, first_batch));
+    COX_HIP(hipEventRecord(X.ev[0], s));
+    sweep += first_batch;
+    for (int k = 0;; ++k) {
+      const int checked_last = sweep - 1;  // last sweep of the batch whose flags event k carries
+      if (sweep + kNextBatch + 1 > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
+      COX_TRY(enqueue(sweep, kNextBatch));
+      COX_HIP(hipEventRecord(X.ev[(k + 1) & 1], s));
+      sweep += kNextBatch;
+      COX_HIP(hipEventSynchronize(X.ev[k & 1]));
+      if (X.h_changed[checked_last] == 0) break;
     }
-    COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
-    return COX_OK;
-  };
-  // The host looks at the "changed" flags one batch behind what it has enqueued: the next batch is already queued while it
-  // waits for the previous one's flags, so the GPU never idles for the round trip.  Sweeps that run after convergence
-  // reproduce the fixed point, so the (at most kNextBatch) speculative sweeps cost time but cannot change the result.
-  int sweep = 0;  // sweeps enqueued
-  if (kFirstBatch + kNextBatch > kFastMaxSweeps) return COX_ERR_INTERNAL;
-  COX_TRY(enqueue(0, kFirstBatch));
-  COX_HIP(hipEventRecord(X.ev[0], s));
-  sweep = kFirstBatch;
-  for (int k = 0;; ++k) {
-    const int checked_last = sweep - 1;  // last sweep of the batch whose flags event k carries
-    if (sweep + kNextBatch > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
-    COX_TRY(enqueue(sweep, kNextBatch));
-    COX_HIP(hipEventRecord(X.ev[(k + 1) & 1], s));
-    sweep += kNextBatch;
-    COX_HIP(hipEventSynchronize(X.ev[k & 1]));
-    if (X.h_changed[checked_last] == 0) break;
+    if (X.cap0 == 0xFFFFFFFFu) break;  // whole walks from the start: nothing to grow
+    // did a ray reach the end of its candidate list without stopping?  (flag in the next free slot of the sweep flags)
+    hipLaunchKernelGGL(k_fast_grow_caps, gr, dim3(256), 0, s, F.rays.nsteps, X.cap, X.reach[sweep & 1], X.reach[(sweep + 1) & 1], X.d_changed + sweep, F.cnt);
+    COX_HIP(hipMemcpyAsync(X.h_changed + sweep, X.d_changed + sweep, sizeof(u32), hipMemcpyDeviceToHost, s));
+    COX_HIP(hipStreamSynchronize(s));
+    const bool grew = X.h_changed[sweep] != 0;
+    sweep += 1;  // the slot is used up; keeps the parity bookkeeping simple: both reach buffers hold the same values here
+    if (!grew) break;
   }
   X.sweeps_total += static_cast<uint64_t>(sweep);
   X.frames += 1;
@@ -1994,7 +2020,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   {
     FastState& X = I->fast;
     for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
-                    static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.vray), static_cast<void*>(X.sray), static_cast<void*>(X.sstep), static_cast<void*>(X.shash), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
+                    static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.cap), static_cast<void*>(X.vray), static_cast<void*>(X.sray), static_cast<void*>(X.sstep), static_cast<void*>(X.shash), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
                     static_cast<void*>(X.tmax), static_cast<void*>(X.reach[0]), static_cast<void*>(X.reach[1]),
                     static_cast<void*>(X.d_changed)})
       ptrs.push_back(q);
