@@ -148,6 +148,37 @@ class Layer:
                            "layer_registration_points")
         return out
 
+    def reserve(self, capacity_blocks):
+        self.eng.check(self.eng.fn("layer_reserve")(self.h, C.c_uint64(capacity_blocks)), "layer_reserve")
+
+    def capacity(self):
+        n = C.c_uint64()
+        self.eng.check(self.eng.fn("layer_capacity")(self.h, C.byref(n)), "layer_capacity")
+        return int(n.value)
+
+    def set_auto_grow(self, on):
+        self.eng.check(self.eng.fn("layer_set_auto_grow")(self.h, C.c_int(int(on))), "layer_set_auto_grow")
+
+    def clone_to_device(self, device, capacity_blocks=0):
+        """Submap hand-over inside one process: block array + keys copied GPU to GPU, hash rebuilt on `device`."""
+        out = Layer.__new__(Layer)
+        out.eng, out.voxel_size, out.h = self.eng, self.voxel_size, C.c_void_p()
+        self.eng.check(self.eng.fn("layer_clone_to_device")(self.h, C.c_int(device), C.c_uint64(capacity_blocks), C.byref(out.h)), "layer_clone_to_device")
+        return out
+
+    def n_blocks(self):
+        return self.stats()[0]
+
+    def export_dev(self, idx_ptr, vox_ptr, cap_blocks):
+        """serializeLayerAsMsg into device buffers (pointers as ints); returns the block count."""
+        n = C.c_uint64()
+        self.eng.check(self.eng.fn("layer_export_dev")(self.h, C.c_void_p(idx_ptr), C.c_void_p(vox_ptr), C.c_uint64(cap_blocks), C.byref(n)), "layer_export_dev")
+        return int(n.value)
+
+    def upload_dev(self, idx_ptr, vox_ptr, n_blocks, action=0):
+        """deserializeMsgToLayer from device buffers (pointers as ints)."""
+        self.eng.check(self.eng.fn("layer_upload_dev")(self.h, C.c_void_p(idx_ptr), C.c_void_p(vox_ptr), C.c_uint64(n_blocks), C.c_int(action)), "layer_upload_dev")
+
     def upload(self, idx, vox, action=0):
         idx = np.ascontiguousarray(idx, np.int32)
         vox = np.ascontiguousarray(vox, np.uint32)
@@ -199,6 +230,10 @@ class Integrator:
         self.eng.check(self.eng.fn("integrate_depth_dev")(self.h, _fp(T), C.c_void_p(depth_ptr), C.c_void_p(rgba_ptr or 0),
                                                           C.c_int(w), C.c_int(h), _fp(K)), "integrate_depth_dev")
 
+    def set_input_stream(self, stream_ptr, enable=True):
+        """Order *_dev calls against the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self.eng.check(self.eng.fn("integrator_set_input_stream")(self.h, C.c_void_p(stream_ptr or 0), C.c_int(int(enable))), "integrator_set_input_stream")
+
     def sync(self):
         self.eng.check(self.eng.fn("integrator_sync")(self.h), "integrator_sync")
 
@@ -245,6 +280,38 @@ class RegPoints:
         eng.check(eng.fn("regpoints_size")(self.h, C.byref(n)), "regpoints_size")
         self.n = int(n.value)
         return self
+
+    @classmethod
+    def _wrap(cls, eng, h):
+        self = cls.__new__(cls)
+        self.eng, self.h = eng, h
+        n = C.c_uint64()
+        eng.check(eng.fn("regpoints_size")(self.h, C.byref(n)), "regpoints_size")
+        self.n = int(n.value)
+        return self
+
+    @classmethod
+    def from_device(cls, eng, ptr, n, device=0):
+        """A set whose n*5 floats already sit in HBM (pointer as int)."""
+        h = C.c_void_p()
+        eng.check(eng.fn("regpoints_create_dev")(C.c_int(device), C.c_void_p(ptr), C.c_uint64(n), C.byref(h)), "regpoints_create_dev")
+        return cls._wrap(eng, h)
+
+    def clone_to_device(self, device):
+        h = C.c_void_p()
+        self.eng.check(self.eng.fn("regpoints_clone_to_device")(self.h, C.c_int(device), C.byref(h)), "regpoints_clone_to_device")
+        return RegPoints._wrap(self.eng, h)
+
+    def data_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self.eng.check(self.eng.fn("regpoints_data_dev")(self.h, C.byref(p), C.byref(n)), "regpoints_data_dev")
+        return int(p.value or 0), int(n.value)
+
+    def download(self):
+        out = np.zeros((self.n, 5), np.float32)
+        n = C.c_uint64()
+        self.eng.check(self.eng.fn("regpoints_download")(self.h, _fp(out), C.c_uint64(self.n), C.byref(n)), "regpoints_download")
+        return out
 
     def close(self):
         if self.h:

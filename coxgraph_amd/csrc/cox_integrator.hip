@@ -497,7 +497,9 @@ __global__ void __launch_bounds__(256) k_touch(const FrameParams* __restrict__ P
           L.block_keys[pool] = bkey;
           atomicAdd(&cnt->n_new_blocks, 1u);
         } else {
-          atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped
+          atomicSub(L.d_nblocks, 1u);     // the counter settles at the capacity
+          atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped, and every later
+                                          // frame that meets the key reports the error again (emit kernels)
         }
       }
       if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
@@ -560,6 +562,7 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
           last_bkey = bkey;
           const u32 slot = ht_find(L.ht_keys, L.ht_mask, bkey);
           last_ord = (slot != kInvalid && L.ht_vals[slot] != kInvalid) ? L.ht_ord[slot] : kInvalid;
+          if (last_ord == kInvalid) atomicOr(&cnt->err, kErrPool);  // block without storage: this update is lost
         }
         if (last_ord != kInvalid) vid = (last_ord << 12) | static_cast<u32>((x & 15) | ((y & 15) << 4) | ((z & 15) << 8));
       }
@@ -685,7 +688,9 @@ __device__ __forceinline__ void touch_block(const FrameParams& P, const LayerVie
       L.block_keys[pool] = bkey;
       atomicAdd(&cnt->n_new_blocks, 1u);
     } else {
-      atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped
+      atomicSub(L.d_nblocks, 1u);     // the counter settles at the capacity
+      atomicOr(layer_err, kErrPool);  // ht_vals[slot] stays kInvalid: updates to this block are dropped, and every later
+                                      // frame that meets the key reports the error again (emit kernels)
     }
   }
   if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
@@ -817,6 +822,7 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
         if (is_head) {
           const u32 slot = ht_find(L.ht_keys, L.ht_mask, bkey);
           ord = (slot != kInvalid && L.ht_vals[slot] != kInvalid) ? L.ht_ord[slot] : kInvalid;
+          if (ord == kInvalid) atomicOr(&cnt->err, kErrPool);  // block without storage: this update is lost
         }
         // every lane takes the ordinal of the nearest head at or below it, or the carry of the previous round
         const u64 heads = __ballot(is_head);
@@ -844,6 +850,7 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
             last_bkey = bkey;
             const u32 slot = ht_find(L.ht_keys, L.ht_mask, bkey);
             last_ord = (slot != kInvalid && L.ht_vals[slot] != kInvalid) ? L.ht_ord[slot] : kInvalid;
+            if (last_ord == kInvalid) atomicOr(&cnt->err, kErrPool);  // block without storage: this update is lost
           }
           if (last_ord != kInvalid) vid = (last_ord << 12) | static_cast<u32>((x & 15) | ((y & 15) << 4) | ((z & 15) << 8));
         }
@@ -1114,10 +1121,14 @@ __device__ __forceinline__ void replay_piece(const FrameParams& P, const RayArra
 }
 __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ touched_slots, RecordView V,
                                                     const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
-                                                    const u32* __restrict__ piece_wsum, Counters* cnt, u32* layer_err) {
+                                                    const u32* __restrict__ piece_wsum, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
   const FrameParams P = *Pp;
-  // last kernel of the frame: make this frame's error bits sticky until the host next looks
-  if (blockIdx.x == 0 && threadIdx.x == 0 && cnt->err) atomicOr(layer_err, cnt->err);
+  // last kernel of the frame: make this frame's error bits sticky until the host next looks, and leave the layer's block
+  // count where the host can read it without a sync (pinned word; it decides when to grow the pool)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (cnt->err) atomicOr(layer_err, cnt->err);
+    *h_nblocks = min(*L.d_nblocks, L.capacity);
+  }
   const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
   if (n == 0) return;
   const u32 par = uniform_u32(V.info->parity & 1u);
@@ -1322,6 +1333,13 @@ struct cox_integrator {
   u32 pcap = 0, rcap = 0, fh_cap = 0;
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
   bool small_axis_cap = false;  // no ray can cross more than kAxisCapSmall - 2 planes of one axis
+  u32 layer_generation = 0;     // cox_layer::generation the layer-sized buffers (touched_slots, ord_info, graphs) belong to
+  // ordering against the caller's stream (cox_integrator_set_input_stream): the first stage waits for what the producer has
+  // enqueued, and the producer's stream waits until the engine has read the inputs (stream-ordered allocators may then
+  // recycle them)
+  bool has_producer = false;
+  hipStream_t producer = nullptr;
+  hipEvent_t ev_producer = nullptr, ev_inputs_read = nullptr;
   float* own_xyz = nullptr;  // staging for host / depth inputs
   uint8_t* own_rgba = nullptr;
   u32* depth_flag = nullptr;
@@ -1650,7 +1668,7 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   }
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
   hipLaunchKernelGGL(k_apply_long, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
-                     I->layer->d_err);
+                     I->layer->d_err, I->layer->h_nblocks);
   if (timed) {
     COX_HIP(hipEventRecord(e1, s));
     I->apply_events.emplace_back(e0, e1);
@@ -1792,10 +1810,35 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   return COX_OK;
 }
 
+// Layer::allocateBlockPtrByIndex never fails in voxblox.  The last kernel of every frame leaves the block count in a pinned
+// word; once the pool is half full it is doubled before the next frame is enqueued (a frame that still runs out reports
+// COX_ERR_POOL_EXHAUSTED at sync, and so does every later frame that meets one of its blocks).  The buffers sized by the
+// layer's hash capacity follow the layer whenever it has been reallocated (by this or by cox_layer_reserve / upload).
+static int follow_layer(cox_integrator* I) {
+  cox_layer* Lh = I->layer;
+  if (Lh->auto_grow && static_cast<u64>(*Lh->h_nblocks) * 2 > Lh->capacity && Lh->capacity < (1ull << 26)) {
+    COX_TRY(sync_all(I));
+    const int st = cox_internal_layer_reserve(Lh, std::min<u64>(2 * Lh->capacity, 1ull << 26));
+    if (st != COX_OK && st != COX_ERR_OUT_OF_MEMORY) return st;  // out of memory: carry on with what there is
+    if (st == COX_ERR_OUT_OF_MEMORY) Lh->auto_grow = false;
+  }
+  if (I->layer_generation != Lh->generation) {
+    COX_TRY(sync_all(I));
+    drop_graphs(I);
+    for (RecordSet& S : I->rs) {
+      COX_TRY(dev_realloc(&S.touched_slots, Lh->ht_cap));
+      COX_TRY(dev_realloc(&S.ord_info, Lh->ht_cap));
+    }
+    I->layer_generation = Lh->generation;
+  }
+  return COX_OK;
+}
+
 // enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
 static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
   cox_layer* Lh = I->layer;
   COX_TRY(ensure_capacity(I, n));
+  COX_TRY(follow_layer(I));
   I->last = cox_frame_stats{};
   I->last.n_points = n;
   I->last_has_counts = false;
@@ -1812,10 +1855,17 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   P.frame_id = ++Lh->frame_id;
   I->h_params[slot] = P;
 
+  if (I->has_producer) {  // inputs written on the caller's stream: stage A1 starts after them
+    COX_HIP(hipEventRecord(I->ev_producer, I->producer));
+    COX_HIP(hipStreamWaitEvent(I->st[0], I->ev_producer, 0));
+  }
   if (I->method == COX_METHOD_FAST) {  // single stream, see fast_frame
     COX_TRY(fast_frame(ctx, I->st[0]));
     COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
     COX_HIP(hipEventRecord(F.done, I->st[0]));
+    COX_HIP(hipEventRecord(Lh->last_write, I->st[0]));
+    Lh->has_write = true;
+    if (I->has_producer) COX_HIP(hipStreamWaitEvent(I->producer, F.done, 0));  // the sweeps re-read nothing, but the record stage does
     F.used = true;
     I->last_has_counts = true;
     COX_HIP(hipGetLastError());
@@ -1835,6 +1885,10 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   COX_HIP(hipEventRecord(I->ev_a2, I->st[1]));
   COX_HIP(hipEventRecord(B.done, I->st[1]));
   B.used = true;
+  if (I->has_producer) {  // the inputs are not read after A2: later work on the caller's stream may overwrite / free them
+    COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[1]));
+    COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
+  }
   // B1
   COX_HIP(hipStreamWaitEvent(I->st[2], I->ev_a2, 0));
   if (S.used && I->st[3] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[2], S.done, 0));  // frame t-2's B2 is done with this record set
@@ -1847,6 +1901,8 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   COX_TRY(run_stage(3, ctx));
   COX_HIP(hipEventRecord(F.done, I->st[3]));
   COX_HIP(hipEventRecord(S.done, I->st[3]));
+  COX_HIP(hipEventRecord(Lh->last_write, I->st[3]));
+  Lh->has_write = true;
   F.used = true;
   S.used = true;
   I->last_has_counts = true;
@@ -1953,6 +2009,9 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   ev(&I->ev_a1);
   ev(&I->ev_a2);
   ev(&I->ev_b1);
+  ev(&I->ev_producer);
+  ev(&I->ev_inputs_read);
+  I->layer_generation = layer->generation;
   for (FrameSet& F : I->fs) {
     ev(&F.done);
     ev(&F.params_copied);
@@ -2029,7 +2088,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     for (hipEvent_t e : X.ev)
       if (e) (void)hipEventDestroy(e);
   }
-  std::vector<hipEvent_t> events = {I->ev_a1, I->ev_a2, I->ev_b1};
+  std::vector<hipEvent_t> events = {I->ev_a1, I->ev_a2, I->ev_b1, I->ev_producer, I->ev_inputs_read};
   for (FrameSet& F : I->fs) {
     const RayArrays& R = F.rays;
     for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
@@ -2102,6 +2161,14 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   COX_HIP(hipStreamSynchronize(s));
   const u32 n_pts = tmp->n_depth_points;
   return integrate_device(I, T_G_C, I->own_xyz, I->own_rgba, n_pts, 0);
+}
+
+int cox_integrator_set_input_stream(cox_integrator_t* I, void* hip_stream, int enable) {
+  COX_ENTRY();
+  if (!I) return COX_ERR_INVALID_ARG;
+  I->has_producer = enable != 0;
+  I->producer = static_cast<hipStream_t>(hip_stream);
+  return COX_OK;
 }
 
 int cox_integrator_sync(cox_integrator_t* I) {

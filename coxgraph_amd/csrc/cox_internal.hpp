@@ -54,7 +54,22 @@ struct cox_layer {
   u32* d_nblocks = nullptr;   // device counter
   u32* d_err = nullptr;       // sticky device error bits
   u32 frame_id = 0;           // shared by every integrator on this layer
+  // growth (voxblox's Layer grows without bound): the last kernel of every frame leaves the block count in this pinned
+  // word, so the host can see a pool filling up without a sync and double it before the next frame (cox_layer_reserve)
+  u32* h_nblocks = nullptr;
+  u32 generation = 0;         // bumped whenever the buffers above are reallocated (integrators re-read them)
+  bool auto_grow = true;
+  // recorded by an integrator after the last kernel of every frame it enqueues; readers on other streams
+  // (cox_reg_*, clones) wait for it instead of for the whole device
+  hipEvent_t last_write = nullptr;
+  bool has_write = false;
 };
+
+// make stream s wait for every frame enqueued so far on the layer (no-op when nothing was enqueued)
+static inline void cox_layer_wait_writes(const cox_layer* L, hipStream_t s) {
+  if (L->has_write && L->last_write) (void)hipStreamWaitEvent(s, L->last_write, 0);
+}
+int cox_internal_layer_reserve(cox_layer* L, u64 capacity_blocks);
 
 // voxgraph registration point set of a submap, resident on one GPU
 struct cox_regpoints {

@@ -44,6 +44,7 @@ static int layer_reset_storage(cox_layer* L, u64 used_blocks, hipStream_t s) {
   COX_HIP(hipMemsetAsync(L->d_nblocks, 0, sizeof(u32), s));
   COX_HIP(hipMemsetAsync(L->d_err, 0, sizeof(u32), s));
   L->frame_id = 0;
+  if (L->h_nblocks) *L->h_nblocks = 0;
   return COX_OK;
 }
 
@@ -141,6 +142,9 @@ int cox_layer_create(float voxel_size, int voxels_per_side, int device, uint64_t
   alloc(reinterpret_cast<void**>(&L->block_keys), sizeof(u64) * L->capacity);
   alloc(reinterpret_cast<void**>(&L->d_nblocks), sizeof(u32));
   alloc(reinterpret_cast<void**>(&L->d_err), sizeof(u32));
+  if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&L->h_nblocks), sizeof(u32), hipHostMallocDefault) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK && hipEventCreateWithFlags(&L->last_write, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
+  L->auto_grow = std::getenv("COX_NO_GROW") == nullptr;
   if (st == COX_OK) st = layer_reset_storage(L, L->capacity, nullptr);
   if (st == COX_OK && hipDeviceSynchronize() != hipSuccess) st = COX_ERR_NO_DEVICE;
   if (st != COX_OK) {
@@ -163,6 +167,8 @@ void cox_layer_destroy(cox_layer_t* L) {
   (void)hipFree(L->block_keys);
   (void)hipFree(L->d_nblocks);
   (void)hipFree(L->d_err);
+  if (L->h_nblocks) (void)hipHostFree(L->h_nblocks);
+  if (L->last_write) (void)hipEventDestroy(L->last_write);
   delete L;
 }
 
@@ -242,6 +248,7 @@ __global__ void k_upload_insert(u64* ht_keys, u32* ht_vals, u32 ht_mask, u64* bl
   if (fresh) {
     const u32 pool = atomicAdd(d_nblocks, 1u);
     if (pool >= capacity) {
+      atomicSub(d_nblocks, 1u);  // the counter settles at the capacity; the key stays without storage (ht_vals == kInvalid)
       atomicOr(d_err, kErrPool);
       return;
     }
@@ -250,6 +257,7 @@ __global__ void k_upload_insert(u64* ht_keys, u32* ht_vals, u32 ht_mask, u64* bl
     pool_of[i] = pool | 0x80000000u;  // bit 31: fresh (a message never repeats a block)
   } else {
     pool_of[i] = ht_vals[slot];  // block existed before this launch
+    if (pool_of[i] == kInvalid) atomicOr(d_err, kErrPool);  // a key an earlier, exhausted call left without storage: still an error
   }
 }
 // one workgroup per uploaded block; action 0/2: overwrite, 1: mergeVoxelAIntoVoxelB
@@ -279,43 +287,237 @@ __global__ void __launch_bounds__(256) k_upload_copy(u32* __restrict__ voxels, c
   }
 }
 
+// shared tail of the uploads: n blocks whose indices and wire words already sit on the layer's GPU
+static int upload_from_device(cox_layer* L, const int32_t* d_idx, const u32* d_src, u32 n, int action) {
+  // voxblox's Layer grows without bound: make room first (a message never repeats a block, so nb + n is an upper bound)
+  u32 nb0, err0;
+  int st = layer_read_counters(L, &nb0, &err0);
+  if (st != COX_OK) return st;
+  if (static_cast<u64>(nb0) + n > L->capacity) {
+    if (!L->auto_grow) return COX_ERR_POOL_EXHAUSTED;
+    st = cox_internal_layer_reserve(L, std::max<u64>(2 * L->capacity, static_cast<u64>(nb0) + n));
+    if (st != COX_OK) return st == COX_ERR_OUT_OF_MEMORY ? COX_ERR_POOL_EXHAUSTED : st;
+  }
+  u32* d_pool = nullptr;
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pool), sizeof(u32) * n));
+  hipLaunchKernelGGL(k_upload_insert, dim3((n + 255) / 256), dim3(256), 0, nullptr, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->block_keys,
+                     L->d_nblocks, static_cast<u32>(L->capacity), L->d_err, d_idx, n, d_pool);
+  hipLaunchKernelGGL(k_upload_copy, dim3(n), dim3(256), 0, nullptr, L->voxels, d_src, static_cast<const u32*>(nullptr), d_pool, action);
+  COX_HIP(hipDeviceSynchronize());
+  (void)hipFree(d_pool);
+  u32 nb, err;
+  st = layer_read_counters(L, &nb, &err);
+  if (st != COX_OK) return st;
+  *L->h_nblocks = nb;
+  return err_bits_to_status(err);
+}
+
 extern "C" int cox_layer_upload(cox_layer_t* L, const int32_t* block_idx_xyz, const uint32_t* voxels_3u32, uint64_t n_blocks, int action) {
   COX_ENTRY();
-  if (!L || action < 0 || action > 2 || (n_blocks && (!block_idx_xyz || !voxels_3u32))) return COX_ERR_INVALID_ARG;
+  if (!L || action < 0 || action > 2 || (n_blocks && (!block_idx_xyz || !voxels_3u32)) || n_blocks > (1ull << 26)) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(L->device));
   if (action == 2) {
     int st = cox_layer_clear(L);
     if (st != COX_OK) return st;
   }
   if (n_blocks == 0) return COX_OK;
-  if (n_blocks > L->capacity) return COX_ERR_POOL_EXHAUSTED;
   const size_t block_words = static_cast<size_t>(kVoxelsPerBlock) * kWordsPerVoxel;
   int32_t* d_idx = nullptr;
-  u32 *d_src = nullptr, *d_pool = nullptr;
+  u32* d_src = nullptr;
   COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), sizeof(int32_t) * 3 * n_blocks));
-  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pool), sizeof(u32) * n_blocks));
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_src), sizeof(u32) * block_words * n_blocks);
   if (e != hipSuccess) {
     (void)hipFree(d_idx);
-    (void)hipFree(d_pool);
     return COX_ERR_OUT_OF_MEMORY;
   }
   COX_HIP(hipMemcpy(d_idx, block_idx_xyz, sizeof(int32_t) * 3 * n_blocks, hipMemcpyHostToDevice));
   COX_HIP(hipMemcpy(d_src, voxels_3u32, sizeof(u32) * block_words * n_blocks, hipMemcpyHostToDevice));
-  const u32 n = static_cast<u32>(n_blocks);
-  hipLaunchKernelGGL(k_upload_insert, dim3((n + 255) / 256), dim3(256), 0, nullptr, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->block_keys,
-                     L->d_nblocks, static_cast<u32>(L->capacity), L->d_err, d_idx, n, d_pool);
-  hipLaunchKernelGGL(k_upload_copy, dim3(n), dim3(256), 0, nullptr, L->voxels, d_src, static_cast<const u32*>(nullptr), d_pool, action);
-  COX_HIP(hipDeviceSynchronize());
+  const int st = upload_from_device(L, d_idx, d_src, static_cast<u32>(n_blocks), action);
   (void)hipFree(d_idx);
   (void)hipFree(d_src);
-  (void)hipFree(d_pool);
+  return st;
+}
+
+// deserializeMsgToLayer from a message that already sits in HBM (the submap hand-over between GPUs: the wire arrays
+// arrive by RCCL all-gather / peer copy and never touch the host)
+extern "C" int cox_layer_upload_dev(cox_layer_t* L, const int32_t* block_idx_xyz_dev, const uint32_t* voxels_3u32_dev, uint64_t n_blocks, int action) {
+  COX_ENTRY();
+  if (!L || action < 0 || action > 2 || (n_blocks && (!block_idx_xyz_dev || !voxels_3u32_dev)) || n_blocks > (1ull << 26)) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(L->device));
+  COX_HIP(hipDeviceSynchronize());  // the producer of the device buffers (any stream) is done after this
+  if (action == 2) {
+    int st = cox_layer_clear(L);
+    if (st != COX_OK) return st;
+  }
+  if (n_blocks == 0) return COX_OK;
+  return upload_from_device(L, block_idx_xyz_dev, voxels_3u32_dev, static_cast<u32>(n_blocks), action);
+}
+
+// ---- growth -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rehash(const u64* __restrict__ block_keys, u32 n, u64* __restrict__ ht_keys, u32* __restrict__ ht_vals, u32 ht_mask,
+                                                u32* d_err) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool fresh;
+  const u32 slot = ht_insert(ht_keys, ht_mask, block_keys[i], &fresh);
+  if (slot == kInvalid) {
+    atomicOr(d_err, kErrTable);
+    return;
+  }
+  ht_vals[slot] = i;
+}
+
+// Layer::allocateBlockPtrByIndex never fails in voxblox; here the pool and the hash table are reallocated at (at least)
+// capacity_blocks, the blocks copied over and the table rebuilt from block_keys.  Keys that an exhausted frame left without
+// storage are dropped by the rebuild.  Nothing may be in flight on the layer (the caller has synchronised its streams).
+int cox_internal_layer_reserve(cox_layer* L, u64 capacity_blocks) {
+  if (capacity_blocks <= L->capacity) return COX_OK;
+  if (capacity_blocks > (1ull << 26)) return COX_ERR_INVALID_ARG;
+  u32 nb, err;
+  int st = layer_read_counters(L, &nb, &err);  // device-wide sync
+  if (st != COX_OK) return st;
+  const size_t block_bytes = static_cast<size_t>(kVoxelsPerBlock) * kWordsPerVoxel * sizeof(u32);
+  const u32 ht_cap = std::max<u32>(1024, next_pow2(2 * capacity_blocks));
+  u32 *voxels = nullptr, *ht_vals = nullptr, *ht_stamp = nullptr, *ht_ord = nullptr;
+  u64 *ht_keys = nullptr, *block_keys = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&voxels), capacity_blocks * block_bytes) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&ht_keys), sizeof(u64) * ht_cap) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&ht_vals), sizeof(u32) * ht_cap) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&ht_stamp), sizeof(u32) * ht_cap) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&ht_ord), sizeof(u32) * ht_cap) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&block_keys), sizeof(u64) * capacity_blocks) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    for (void* q : {static_cast<void*>(voxels), static_cast<void*>(ht_keys), static_cast<void*>(ht_vals), static_cast<void*>(ht_stamp), static_cast<void*>(ht_ord),
+                    static_cast<void*>(block_keys)})
+      if (q) (void)hipFree(q);
+    return COX_ERR_OUT_OF_MEMORY;
+  }
+  if (nb) COX_HIP(hipMemcpy(voxels, L->voxels, nb * block_bytes, hipMemcpyDeviceToDevice));
+  COX_HIP(hipMemset(reinterpret_cast<char*>(voxels) + nb * block_bytes, 0, (capacity_blocks - nb) * block_bytes));
+  if (nb) COX_HIP(hipMemcpy(block_keys, L->block_keys, sizeof(u64) * nb, hipMemcpyDeviceToDevice));
+  COX_HIP(hipMemset(ht_keys, 0xFF, sizeof(u64) * ht_cap));
+  COX_HIP(hipMemset(ht_vals, 0xFF, sizeof(u32) * ht_cap));
+  COX_HIP(hipMemset(ht_stamp, 0, sizeof(u32) * ht_cap));
+  COX_HIP(hipMemset(ht_ord, 0, sizeof(u32) * ht_cap));
+  COX_HIP(hipMemcpy(L->d_nblocks, &nb, sizeof(u32), hipMemcpyHostToDevice));  // also undoes a transient overshoot
+  if (nb) hipLaunchKernelGGL(k_rehash, dim3((nb + 255) / 256), dim3(256), 0, nullptr, block_keys, nb, ht_keys, ht_vals, ht_cap - 1, L->d_err);
+  COX_HIP(hipDeviceSynchronize());
+  for (void* q : {static_cast<void*>(L->voxels), static_cast<void*>(L->ht_keys), static_cast<void*>(L->ht_vals), static_cast<void*>(L->ht_stamp),
+                  static_cast<void*>(L->ht_ord), static_cast<void*>(L->block_keys)})
+    (void)hipFree(q);
+  L->voxels = voxels;
+  L->ht_keys = ht_keys;
+  L->ht_vals = ht_vals;
+  L->ht_stamp = ht_stamp;
+  L->ht_ord = ht_ord;
+  L->block_keys = block_keys;
+  L->capacity = capacity_blocks;
+  L->ht_cap = ht_cap;
+  L->generation += 1;
+  *L->h_nblocks = nb;
+  return COX_OK;
+}
+
+extern "C" int cox_layer_reserve(cox_layer_t* L, uint64_t capacity_blocks) {
+  COX_ENTRY();
+  if (!L) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(L->device));
+  return cox_internal_layer_reserve(L, capacity_blocks);
+}
+extern "C" int cox_layer_capacity(cox_layer_t* L, uint64_t* capacity_blocks) {
+  if (!L || !capacity_blocks) return COX_ERR_INVALID_ARG;
+  *capacity_blocks = L->capacity;
+  return COX_OK;
+}
+extern "C" int cox_layer_set_auto_grow(cox_layer_t* L, int on) {
+  if (!L) return COX_ERR_INVALID_ARG;
+  L->auto_grow = on != 0;
+  return COX_OK;
+}
+
+// ---- submap hand-over between GPUs -----------------------------------------------
+// The reference's server pulls whole submaps from the clients as ROS messages (coxgraph/src/server/client_handler.cpp:82-104,
+// coxgraph_server.cpp:253-258).  Here the block array and the block keys go GPU to GPU (hipMemcpyPeer: xGMI between
+// the GPUs of a node, a plain device copy on one GPU) and the destination rebuilds its hash table -- device layout ==
+// wire layout, so there is nothing to (de)serialise.
+extern "C" int cox_layer_clone_to_device(const cox_layer_t* src_, int dst_device, uint64_t capacity_blocks, cox_layer_t** out) {
+  COX_ENTRY();
+  cox_layer* src = const_cast<cox_layer*>(src_);
+  if (!src || !out) return COX_ERR_INVALID_ARG;
+  u32 nb, err;
+  int st = layer_read_counters(src, &nb, &err);  // waits for everything in flight on the source GPU
+  if (st != COX_OK) return st;
+  if (err) return err_bits_to_status(err);
+  const u64 cap = std::max<u64>(std::max<u64>(capacity_blocks, nb), 64);
+  cox_layer* dst = nullptr;
+  st = cox_layer_create(src->voxel_size, kVps, dst_device, cap, &dst);
+  if (st != COX_OK) return st;
+  if (nb) {
+    const size_t block_bytes = static_cast<size_t>(kVoxelsPerBlock) * kWordsPerVoxel * sizeof(u32);
+    hipError_t e = hipMemcpyPeer(dst->voxels, dst_device, src->voxels, src->device, nb * block_bytes);
+    if (e == hipSuccess) e = hipMemcpyPeer(dst->block_keys, dst_device, src->block_keys, src->device, sizeof(u64) * nb);
+    if (e == hipSuccess) e = hipSetDevice(dst_device);
+    if (e == hipSuccess) e = hipMemcpy(dst->d_nblocks, &nb, sizeof(u32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      fprintf(stderr, "[coxgraph_hip] cox_layer_clone_to_device: %s\n", hipGetErrorString(e));
+      cox_layer_destroy(dst);
+      return COX_ERR_NO_DEVICE;
+    }
+    hipLaunchKernelGGL(k_rehash, dim3((nb + 255) / 256), dim3(256), 0, nullptr, dst->block_keys, nb, dst->ht_keys, dst->ht_vals, dst->ht_cap - 1, dst->d_err);
+    if (hipDeviceSynchronize() != hipSuccess) {
+      cox_layer_destroy(dst);
+      return COX_ERR_NO_DEVICE;
+    }
+    *dst->h_nblocks = nb;
+  }
+  (void)hipSetDevice(src->device);
+  *out = dst;
+  return COX_OK;
+}
+
+// one workgroup per block: pool block order[i] -> wire position i
+__global__ void __launch_bounds__(256) k_export_blocks(const u32* __restrict__ voxels, const u64* __restrict__ block_keys, const u32* __restrict__ order,
+                                                       int32_t* __restrict__ idx_out, u32* __restrict__ vox_out) {
+  const u32 i = blockIdx.x;
+  const u32 pool = order[i];
+  const u32* s = voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
+  u32* d = vox_out + static_cast<size_t>(i) * kVoxelsPerBlock * kWordsPerVoxel;
+  for (u32 k = threadIdx.x; k < kVoxelsPerBlock * kWordsPerVoxel; k += 256) d[k] = s[k];
+  if (threadIdx.x == 0) {
+    int x, y, z;
+    unpack_key(block_keys[pool], &x, &y, &z);
+    idx_out[3 * i] = x;
+    idx_out[3 * i + 1] = y;
+    idx_out[3 * i + 2] = z;
+  }
+}
+// serializeLayerAsMsg into DEVICE buffers (same (z,y,x) block order as cox_layer_download): what a rank hands to the
+// all-gather of the submap exchange
+extern "C" int cox_layer_export_dev(cox_layer_t* L, int32_t* block_idx_xyz_dev, uint32_t* voxels_3u32_dev, uint64_t cap_blocks, uint64_t* n_blocks) {
+  COX_ENTRY();
+  if (!L) return COX_ERR_INVALID_ARG;
   u32 nb, err;
   int st = layer_read_counters(L, &nb, &err);
   if (st != COX_OK) return st;
+  if (n_blocks) *n_blocks = nb;
+  if (cap_blocks == 0 && !block_idx_xyz_dev && !voxels_3u32_dev) return err_bits_to_status(err);
+  if (cap_blocks < nb) return COX_ERR_BUFFER_TOO_SMALL;
+  if (nb == 0) return err_bits_to_status(err);
+  if (!block_idx_xyz_dev || !voxels_3u32_dev) return COX_ERR_INVALID_ARG;
+  std::vector<u64> keys(nb);
+  COX_HIP(hipMemcpy(keys.data(), L->block_keys, sizeof(u64) * nb, hipMemcpyDeviceToHost));
+  std::vector<u32> order(nb);
+  for (u32 i = 0; i < nb; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return keys[a] < keys[b]; });
+  u32* d_order = nullptr;
+  COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_order), sizeof(u32) * nb));
+  COX_HIP(hipMemcpy(d_order, order.data(), sizeof(u32) * nb, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_export_blocks, dim3(nb), dim3(256), 0, nullptr, L->voxels, L->block_keys, d_order, block_idx_xyz_dev, voxels_3u32_dev);
+  COX_HIP(hipDeviceSynchronize());
+  (void)hipFree(d_order);
   return err_bits_to_status(err);
 }
-
 
 // =================================================================================================
 // registration points of a finished submap ("voxels" / implicit_to_implicit set)
@@ -632,6 +834,15 @@ __global__ void __launch_bounds__(256) k_resample_blocks(LayerConstView A, Rigid
 // merge n device-resident blocks (indices d_idx, words src[src_index[i]]) into L, voxel by voxel
 static int merge_device_blocks(cox_layer* L, const int32_t* d_idx, const u32* d_src, const u32* d_src_index, u32 n) {
   if (n == 0) return COX_OK;
+  {
+    u32 nb0, err0;
+    int st0 = layer_read_counters(L, &nb0, &err0);
+    if (st0 != COX_OK) return st0;
+    if (static_cast<u64>(nb0) + n > L->capacity && L->auto_grow) {
+      st0 = cox_internal_layer_reserve(L, std::max<u64>(2 * L->capacity, static_cast<u64>(nb0) + n));
+      if (st0 != COX_OK && st0 != COX_ERR_OUT_OF_MEMORY) return st0;
+    }
+  }
   u32* d_pool = nullptr;
   COX_HIP(hipMalloc(reinterpret_cast<void**>(&d_pool), sizeof(u32) * n));
   hipLaunchKernelGGL(k_upload_insert, dim3((n + 255) / 256), dim3(256), 0, nullptr, L->ht_keys, L->ht_vals, L->ht_cap - 1, L->block_keys, L->d_nblocks,
@@ -759,5 +970,6 @@ extern "C" int cox_layer_merge(const cox_layer_t* A_, const float T_B_A[7], cox_
   u32 nb, err;
   st = layer_read_counters(B, &nb, &err);
   if (st != COX_OK) return st;
+  *B->h_nblocks = nb;
   return err_bits_to_status(err);
 }

@@ -363,6 +363,75 @@ int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, c
   *out = R;
   return COX_OK;
 }
+// registration points that already sit in HBM (the submap exchange: another rank's set arrives by all-gather / peer copy)
+int cox_regpoints_create_dev(int device, const float* xyz_dist_weight_dev, uint64_t n, cox_regpoints_t** out) {
+  COX_ENTRY();
+  if (!out || (n && !xyz_dist_weight_dev) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return COX_ERR_NO_DEVICE;
+  COX_HIP(hipSetDevice(device));
+  COX_HIP(hipDeviceSynchronize());  // whatever produced the buffer is done after this
+  cox_regpoints* R = new (std::nothrow) cox_regpoints();
+  if (!R) return COX_ERR_OUT_OF_MEMORY;
+  R->device = device;
+  R->n = n;
+  if (n) {
+    if (hipMalloc(reinterpret_cast<void**>(&R->pts), sizeof(float) * 5 * n) != hipSuccess) {
+      delete R;
+      return COX_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemcpy(R->pts, xyz_dist_weight_dev, sizeof(float) * 5 * n, hipMemcpyDeviceToDevice) != hipSuccess) {
+      (void)hipFree(R->pts);
+      delete R;
+      return COX_ERR_NO_DEVICE;
+    }
+  }
+  *out = R;
+  return COX_OK;
+}
+// device pointer to the n * 5 floats (valid until the set is destroyed): what a rank hands to the all-gather
+int cox_regpoints_data_dev(const cox_regpoints_t* R, const float** xyz_dist_weight_dev, uint64_t* n) {
+  if (!R || !xyz_dist_weight_dev) return COX_ERR_INVALID_ARG;
+  *xyz_dist_weight_dev = R->pts;
+  if (n) *n = R->n;
+  return COX_OK;
+}
+// host copy of a set (tests, hand-over to a mesher): n * 5 floats
+int cox_regpoints_download(const cox_regpoints_t* R, float* xyz_dist_weight, uint64_t cap, uint64_t* n) {
+  COX_ENTRY();
+  if (!R) return COX_ERR_INVALID_ARG;
+  if (n) *n = R->n;
+  if (!xyz_dist_weight) return COX_OK;
+  if (cap < R->n) return COX_ERR_BUFFER_TOO_SMALL;
+  COX_HIP(hipSetDevice(R->device));
+  if (R->n) COX_HIP(hipMemcpy(xyz_dist_weight, R->pts, sizeof(float) * 5 * R->n, hipMemcpyDeviceToHost));
+  return COX_OK;
+}
+// the point set on another GPU of the node (hipMemcpyPeer: xGMI; same device: a plain copy)
+int cox_regpoints_clone_to_device(const cox_regpoints_t* src, int dst_device, cox_regpoints_t** out) {
+  COX_ENTRY();
+  if (!src || !out) return COX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || dst_device < 0 || dst_device >= ndev) return COX_ERR_NO_DEVICE;
+  COX_HIP(hipSetDevice(dst_device));
+  cox_regpoints* R = new (std::nothrow) cox_regpoints();
+  if (!R) return COX_ERR_OUT_OF_MEMORY;
+  R->device = dst_device;
+  R->n = src->n;
+  if (src->n) {
+    if (hipMalloc(reinterpret_cast<void**>(&R->pts), sizeof(float) * 5 * src->n) != hipSuccess) {
+      delete R;
+      return COX_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemcpyPeer(R->pts, dst_device, src->pts, src->device, sizeof(float) * 5 * src->n) != hipSuccess) {
+      (void)hipFree(R->pts);
+      delete R;
+      return COX_ERR_NO_DEVICE;
+    }
+  }
+  *out = R;
+  return COX_OK;
+}
 int cox_regpoints_size(const cox_regpoints_t* R, uint64_t* n) {
   if (!R || !n) return COX_ERR_INVALID_ARG;
   *n = R->n;
@@ -379,7 +448,7 @@ int cox_reg_create(const cox_regpoints_t* reference, const cox_layer_t* reading,
   COX_ENTRY();
   if (!reference || !reading || !out) return COX_ERR_INVALID_ARG;
   const cox_layer* L = reinterpret_cast<const cox_layer*>(reading);
-  if (L->device != reference->device) return COX_ERR_INVALID_ARG;  // exchange submaps first
+  if (L->device != reference->device) return COX_ERR_INVALID_ARG;  // hand the submap over first: cox_layer_clone_to_device / cox_regpoints_clone_to_device
   COX_HIP(hipSetDevice(L->device));
   cox_reg* G = new (std::nothrow) cox_reg();
   if (!G) return COX_ERR_OUT_OF_MEMORY;
@@ -426,6 +495,7 @@ int cox_reg_evaluate(cox_reg_t* G, const double pose_ref[4], const double pose_r
   COX_TRY(dev_grow(&G->d_small, &G->small_cap, static_cast<u64>(nb) + 2));
   const RelPose P = make_rel_pose(pose_ref, pose_read);
   hipStream_t s = G->stream;
+  cox_layer_wait_writes(G->reading, s);  // frames still in flight on the reading layer
   COX_HIP(hipEventRecord(G->ev0, s));
   hipLaunchKernelGGL(k_reg_evaluate, dim3(nb), dim3(kRegThreads), 0, s, reading_view(G->reading), P, G->ref->pts, d_idx, n, G->no_corr_cost,
                      residuals ? G->d_res : nullptr, jac_ref ? G->d_jf : nullptr, jac_read ? G->d_jr : nullptr, G->d_small + 2);
@@ -481,6 +551,7 @@ int cox_reg_normal_eq_begin(cox_reg_t* G, const double pose_ref[4], const double
   COX_TRY(dev_grow(&G->d_small, &G->small_cap, static_cast<u64>(nb) * kPartial + kPartial));
   const RelPose P = make_rel_pose(pose_ref, pose_read);
   hipStream_t s = G->stream;
+  cox_layer_wait_writes(G->reading, s);  // frames still in flight on the reading layer
   COX_HIP(hipEventRecord(G->ev0, s));
   hipLaunchKernelGGL(k_reg_normal_eq, dim3(nb), dim3(kRegThreads), 0, s, reading_view(G->reading), P, G->ref->pts, d_idx, n, G->no_corr_cost,
                      G->d_small + kPartial);

@@ -119,6 +119,26 @@ int cox_layer_download(cox_layer_t* layer, int32_t* block_idx_xyz, uint32_t* vox
  * blocks), 1 = merge (mergeVoxelAIntoVoxelB per voxel), 2 = reset (clear first, then update) */
 int cox_layer_upload(cox_layer_t* layer, const int32_t* block_idx_xyz, const uint32_t* voxels_3u32, uint64_t n_blocks, int action);
 
+/* Layer<TsdfVoxel>::allocateBlockPtrByIndex never fails in voxblox: the map grows without bound.  Here the pool is
+ * doubled automatically (integrators: once it is half full, before the next frame is enqueued; uploads / merges: before
+ * they insert) until hipMalloc refuses; cox_layer_reserve does it explicitly.  Contents are preserved, nothing may be in
+ * flight on the layer from OTHER threads.  cox_layer_set_auto_grow(layer, 0) pins the capacity: a frame that runs out then
+ * reports COX_ERR_POOL_EXHAUSTED at sync, and so does every later frame that meets a block left without storage. */
+int cox_layer_reserve(cox_layer_t* layer, uint64_t capacity_blocks);
+int cox_layer_capacity(cox_layer_t* layer, uint64_t* capacity_blocks);
+int cox_layer_set_auto_grow(cox_layer_t* layer, int on);
+/* deserializeMsgToLayer (utils/msg_converter.h:107) from a message that already sits in HBM on the layer's GPU
+ * (submap hand-over between GPUs: the wire arrays arrive by RCCL all-gather / peer copy) */
+int cox_layer_upload_dev(cox_layer_t* layer, const int32_t* block_idx_xyz_dev, const uint32_t* voxels_3u32_dev, uint64_t n_blocks, int action);
+/* serializeLayerAsMsg (utils/msg_converter.h:49) into DEVICE buffers, same (z,y,x) block order as cox_layer_download:
+ * what a rank hands to the all-gather of the submap exchange.  cap_blocks = 0 and NULL buffers query n_blocks. */
+int cox_layer_export_dev(cox_layer_t* layer, int32_t* block_idx_xyz_dev, uint32_t* voxels_3u32_dev, uint64_t cap_blocks, uint64_t* n_blocks);
+/* Submap hand-over inside one process: what the server obtains with ClientHandler::requestSubmapByTime -> get_client_submap
+ * (src/server/client_handler.cpp:82-104, src/server/coxgraph_server.cpp:253-258) as a ROS message becomes a GPU-to-GPU copy
+ * of the block array + block keys (hipMemcpyPeer: xGMI between the GPUs of a node) and a rebuild of the hash table on
+ * dst_device.  capacity_blocks = 0: as many blocks as the source holds.  Same device: a device-to-device copy. */
+int cox_layer_clone_to_device(const cox_layer_t* src, int dst_device, uint64_t capacity_blocks, cox_layer_t** out);
+
 /* mergeLayerAintoLayerB(layer_A, [T_B_A,] layer_B)  (src/client/map_server.cpp:67-69, src/server/submap_collection.cpp:31-33):
  * T_B_A = NULL merges on the same grid (mergeVoxelAIntoVoxelB per voxel); otherwise A is first resampled onto B's grid
  * (transformLayer: trilinear, nearest voxel where that fails, blocks without data dropped).  Both layers on one GPU. */
@@ -132,7 +152,16 @@ void cox_integrator_destroy(cox_integrator_t* integ);
  * -- the call at coxgraph/include/coxgraph/map_comm/tsdf_recover.h:75.
  * xyz: n*3 floats (camera frame), rgba: n*4 bytes or NULL. Host pointers. Synchronous. */
 int cox_integrate_points(cox_integrator_t* integ, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace);
-/* same, inputs already resident on the handle's GPU; asynchronous on the handle's stream */
+/* same, inputs already resident on the handle's GPU; asynchronous.
+ * ORDERING AND LIFETIME of *_dev inputs.  A frame is enqueued on the engine's own non-blocking streams (ray generation and
+ * layer update of consecutive frames overlap), which do not order against any stream of the caller.  Either
+ *  (a) the caller synchronises the stream that produced xyz_dev / rgba_dev / depth_dev before the call and keeps the
+ *      buffers alive and unmodified until cox_integrator_sync (or four more frames have been enqueued), or
+ *  (b) the caller registers its producer stream once with cox_integrator_set_input_stream: every later *_dev call then
+ *      makes the engine wait for what that stream has enqueued so far, and makes that stream wait until the engine has read
+ *      the inputs -- the call behaves as if the read happened on the caller's stream, so a stream-ordered allocator
+ *      (e.g. PyTorch's, for tensors allocated on that stream) may recycle the buffers as soon as the caller drops them.
+ * Readers of the layer (cox_reg_*, cox_regpoints_from_layer, downloads, clones) wait for the frames in flight by themselves. */
 int cox_integrate_points_dev(cox_integrator_t* integ, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace);
 /* depth image front end (what depth_image_proc/point_cloud_xyzrgb does ahead of the tsdf_server,
  * coxgraph/launch/cvg/tsdf_client0_cvg.launch:24-30): p_C = d*((u-cx)/fx,(v-cy)/fy,1), row-major
@@ -140,7 +169,10 @@ int cox_integrate_points_dev(cox_integrator_t* integ, const float T_G_C[7], cons
  * rgba_dev: w*h*4 bytes or NULL.  K = {fx, fy, cx, cy}.  Asynchronous. */
 int cox_integrate_depth_dev(cox_integrator_t* integ, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h,
                             const float K[4]);
-/* wait for the handle's stream; returns any deferred device-side error (pool exhausted, ...) */
+/* hip_stream: the hipStream_t (as void*) the caller produces *_dev inputs on; NULL = the legacy default stream.
+ * enable = 0 returns to contract (a) above. */
+int cox_integrator_set_input_stream(cox_integrator_t* integ, void* hip_stream, int enable);
+/* wait for the handle's streams; returns any deferred device-side error (pool exhausted, ...) */
 int cox_integrator_sync(cox_integrator_t* integ);
 int cox_integrator_last_stats(cox_integrator_t* integ, cox_frame_stats* stats);
 /* HIP-event timing of the bundle-merge and TSDF-update ("apply") kernels on the streams they run on: 0 = off (default),
@@ -167,6 +199,12 @@ typedef struct cox_reg_config {
  * called at utils/msg_converter.h:113): n * {x, y, z, distance, weight} floats. */
 int cox_regpoints_create(int device, const float* xyz_dist_weight, uint64_t n, cox_regpoints_t** out);
 void cox_regpoints_destroy(cox_regpoints_t* pts);
+/* the same from / to buffers in HBM, and the set on another GPU of the node (the reference ships the submap -- and with it
+ * the inputs of finishSubmap() -- as a ROS message, utils/msg_converter.h:46-118; here the finished point set travels) */
+int cox_regpoints_create_dev(int device, const float* xyz_dist_weight_dev, uint64_t n, cox_regpoints_t** out);
+int cox_regpoints_data_dev(const cox_regpoints_t* pts, const float** xyz_dist_weight_dev, uint64_t* n);
+int cox_regpoints_download(const cox_regpoints_t* pts, float* xyz_dist_weight, uint64_t cap, uint64_t* n);
+int cox_regpoints_clone_to_device(const cox_regpoints_t* src, int dst_device, cox_regpoints_t** out);
 /* VoxgraphSubmap::finishSubmap() -> findRelevantVoxelIndices, as triggered for every received submap at
  * utils/msg_converter.h:113: the "voxels" (implicit_to_implicit) registration point set = every voxel with
  * weight > min_voxel_weight and |distance| < max_voxel_distance, position = voxel centre, in (z,y,x) block order and

@@ -508,3 +508,49 @@ int coxo_recover_process_mesh(coxo_meshconv* c, coxo_integrator* integ, const co
   return COX_OK;
 }
 }  // extern "C"
+
+// ---- growth, device-resident uploads and the submap hand-over: in the oracle "device" pointers are host pointers and a
+// clone is a deep copy ----------------------------------------------------------------------------------------------
+extern "C" {
+int coxo_layer_reserve(coxo_layer* l, uint64_t) { return l ? COX_OK : COX_ERR_INVALID_ARG; }
+int coxo_layer_capacity(coxo_layer* l, uint64_t* cap) {
+  if (!l || !cap) return COX_ERR_INVALID_ARG;
+  *cap = ~0ull;  // unordered_map: unbounded
+  return COX_OK;
+}
+int coxo_layer_set_auto_grow(coxo_layer* l, int) { return l ? COX_OK : COX_ERR_INVALID_ARG; }
+int coxo_layer_upload_dev(coxo_layer* l, const int32_t* idx, const uint32_t* vox, uint64_t n, int action) { return coxo_layer_upload(l, idx, vox, n, action); }
+int coxo_layer_export_dev(coxo_layer* l, int32_t* idx, uint32_t* vox, uint64_t cap, uint64_t* n) { return coxo_layer_download(l, idx, vox, cap, n); }
+int coxo_layer_clone_to_device(const coxo_layer* src, int, uint64_t, coxo_layer** out) {
+  if (!src || !out) return COX_ERR_INVALID_ARG;
+  auto* d = new coxo_layer(src->layer.voxel_size, src->layer.vps);
+  for (auto& kv : src->layer.blocks) {
+    Block* b = d->layer.allocateBlock(kv.first);
+    b->voxels = kv.second->voxels;
+  }
+  *out = d;
+  return COX_OK;
+}
+int coxo_regpoints_create_dev(int device, const float* p, uint64_t n, coxo_regpoints** out) { return coxo_regpoints_create(device, p, n, out); }
+int coxo_regpoints_data_dev(const coxo_regpoints* p, const float** data, uint64_t* n) {
+  if (!p || !data) return COX_ERR_INVALID_ARG;
+  *data = p->pts.empty() ? nullptr : &p->pts[0].x;
+  if (n) *n = p->pts.size();
+  return COX_OK;
+}
+int coxo_regpoints_download(const coxo_regpoints* p, float* out, uint64_t cap, uint64_t* n) {
+  if (!p) return COX_ERR_INVALID_ARG;
+  if (n) *n = p->pts.size();
+  if (!out) return COX_OK;
+  if (cap < p->pts.size()) return COX_ERR_BUFFER_TOO_SMALL;
+  if (!p->pts.empty()) std::memcpy(out, p->pts.data(), p->pts.size() * sizeof(RegPoint));
+  return COX_OK;
+}
+int coxo_regpoints_clone_to_device(const coxo_regpoints* src, int, coxo_regpoints** out) {
+  if (!src || !out) return COX_ERR_INVALID_ARG;
+  auto* h = new coxo_regpoints();
+  h->pts = src->pts;
+  *out = h;
+  return COX_OK;
+}
+}  // extern "C"

@@ -146,13 +146,50 @@ def test_all_points_invalid_allocates_nothing(hip):
 
 
 def test_pool_exhaustion_is_reported(hip):
+    """A pinned pool that runs out is an error in the frame that fills it AND in every later frame that meets one of the
+    blocks it could not store (never a partial map behind COX_OK); the block counter never passes the capacity."""
     cfg = hip.default_config(**synth.integrator_overrides(0.05))
     layer = Layer(hip, 0.05, capacity_blocks=8)
+    layer.set_auto_grow(False)
     integ = Integrator(hip, layer, cfg, "merged")
     T, pts, rgba, _ = synth.make_frame(0)
+    for _ in range(3):
+        with pytest.raises(CoxError) as e:
+            integ.integrate_points(T, pts[::4], rgba[::4])
+        assert e.value.status == -4
+        n = C_uint64_blocks(layer)
+        assert n <= 8
+    # the same through a device upload: keys left without storage stay an error
+    idx = np.array([[100 + k, 0, 0] for k in range(4)], np.int32)
     with pytest.raises(CoxError) as e:
-        integ.integrate_points(T, pts[::4], rgba[::4])
+        layer.upload(idx, np.zeros((4, 4096, 3), np.uint32))
     assert e.value.status == -4
+    # growing the pool heals the layer: the rebuilt table drops the keys without storage
+    layer.reserve(4096)
+    assert layer.capacity() == 4096
+    integ.integrate_points(T, pts[::4], rgba[::4])
+    integ.integrate_points(T, pts[::4], rgba[::4])
+
+
+def C_uint64_blocks(layer):
+    import ctypes as C
+    n, b = C.c_uint64(), C.c_uint64()
+    layer.eng.fn("layer_stats")(layer.h, C.byref(n), C.byref(b))  # status ignored: the layer is in its error state
+    return int(n.value)
+
+
+@pytest.mark.parametrize("method", ["merged", "fast"])
+def test_layer_grows_like_the_reference_map(hip, oracle, method):
+    """voxblox's Layer grows without bound: starting from a pool of 8 blocks the engine doubles it as it fills (first frame
+    sized by hand, as a frame cannot be replayed) and ends with the oracle's map, bit for bit."""
+    kw = dict(method=method, voxel=0.05, frames=[0, 10, 20, 30, 40, 50, 60, 70], subsample=3)
+    lb, _, sb = run_frames(oracle, **kw)
+    first = sb[0]["n_new_blocks"]
+    la, _, sa = run_frames(hip, capacity_blocks=first + 1, **kw)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+    assert la.capacity() > first + 1 and la.stats()[0] == lb.stats()[0]
 
 
 def test_unsupported_configurations_are_refused_loudly(hip):
@@ -411,11 +448,11 @@ def test_pool_exactly_full_and_one_block_short(hip, oracle):
     lb, _, _ = run_frames(oracle, **kw)
     need = lb.stats()[0]
     assert need > 50
-    la, _, _ = run_frames(hip, capacity_blocks=need, **kw)
+    la, _, _ = run_frames(hip, capacity_blocks=need, auto_grow=False, **kw)
     rep = compare_layers(la, lb)
     assert rep["bitexact_d"] and rep["bitexact_w"] and la.stats()[0] == need
     with pytest.raises(CoxError) as e:
-        run_frames(hip, capacity_blocks=need - 1, **kw)
+        run_frames(hip, capacity_blocks=need - 1, auto_grow=False, **kw)
     assert e.value.status == -4
 
 

@@ -8,13 +8,15 @@ TOL = 1e-4  # north_star: distances / weights within 1e-4, voxel / block indices
 
 
 def run_frames(eng, method, voxel, frames, capacity_blocks=0, subsample=1, cfg_overrides=None, client=0, n_clients=1,
-               nan_fraction=0.0, noise=False, wh=(640, 480)):
+               nan_fraction=0.0, noise=False, wh=(640, 480), auto_grow=True):
     """Integrate synthetic frames; returns (layer, integrator, [stats per frame])."""
     ov = synth.integrator_overrides(voxel)
     if cfg_overrides:
         ov.update(cfg_overrides)
     cfg = eng.default_config(**ov)
     layer = Layer(eng, voxel, capacity_blocks=capacity_blocks)
+    if not auto_grow:
+        layer.set_auto_grow(False)
     integ = Integrator(eng, layer, cfg, method)
     stats = []
     for t in frames:
