@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 VOXEL = 0.05
 N_CLIENTS = 3
+RING = 12  # clients sit 30 degrees apart on the camera circle, so neighbouring clients see overlapping parts of the room
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +29,7 @@ def client_submaps(hip, oracle):
     for name, eng in (("hip", hip), ("oracle", oracle)):
         layers = []
         for c in range(N_CLIENTS):
-            layer, _, _ = run_frames(eng, method="merged", voxel=VOXEL, frames=range(0, 80, 10), subsample=3, client=c, n_clients=N_CLIENTS,
+            layer, _, _ = run_frames(eng, method="merged", voxel=VOXEL, frames=range(0, 80, 10), subsample=3, client=c, n_clients=RING,
                                      capacity_blocks=4096)
             layers.append(layer)
         out[name] = layers
@@ -43,7 +44,7 @@ def test_clone_is_the_same_submap(hip, client_submaps):
     # the clone is a layer of its own: it keeps working after the source is cleared, and can be integrated into
     cfg = hip.default_config(**synth.integrator_overrides(VOXEL))
     n0 = dst.stats()[0]
-    T, pts, rgba, _ = synth.make_frame(300, client=1, n_clients=N_CLIENTS)
+    T, pts, rgba, _ = synth.make_frame(300, client=1, n_clients=RING)
     Integrator(hip, dst, cfg, "merged").integrate_points(T, pts[::5], rgba[::5])
     assert dst.stats()[0] >= n0
     assert src.stats()[0] == n0
