@@ -48,6 +48,11 @@ class FrameStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class EsdfConfig(C.Structure):
+    """cox_esdf_config (voxblox EsdfIntegrator::Config)."""
+    _fields_ = [("max_distance_m", C.c_float), ("min_distance_m", C.c_float), ("default_distance_m", C.c_float), ("min_weight", C.c_float)]
+
+
 class RegConfig(C.Structure):
     _fields_ = [("no_correspondence_cost", C.c_double)]
 
@@ -146,6 +151,26 @@ class Layer:
         if n.value:
             self.eng.check(f(self.h, C.c_float(min_voxel_weight), C.c_float(max_voxel_distance), _fp(out), C.c_uint64(n.value), C.byref(n)),
                            "layer_registration_points")
+        return out
+
+    def surface_obb(self):
+        """getSubmapFrameSurfaceObb -> (min[3], max[3], n_surface_voxels)."""
+        mn, mx, n = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_uint64()
+        self.eng.check(self.eng.fn("layer_surface_obb")(self.h, _fp(mn), _fp(mx), C.byref(n)), "layer_surface_obb")
+        return mn, mx, int(n.value)
+
+    def esdf(self, max_distance_m=None, min_distance_m=None, default_distance_m=None, min_weight=None):
+        """generateEsdf(): a new layer (TSDF wire layout: distance = ESDF distance, weight = observed, colour word = fixed)."""
+        cfg = EsdfConfig()
+        self.eng.fn("esdf_config_default", None)(C.byref(cfg))
+        for k, v in (("max_distance_m", max_distance_m), ("min_distance_m", min_distance_m), ("default_distance_m", default_distance_m), ("min_weight", min_weight)):
+            if v is not None:
+                setattr(cfg, k, v)
+        if max_distance_m is not None and default_distance_m is None:
+            cfg.default_distance_m = max_distance_m
+        out = Layer.__new__(Layer)
+        out.eng, out.voxel_size, out.h = self.eng, self.voxel_size, C.c_void_p()
+        self.eng.check(self.eng.fn("esdf_from_tsdf")(self.h, C.byref(cfg), C.byref(out.h)), "esdf_from_tsdf")
         return out
 
     def reserve(self, capacity_blocks):
@@ -297,6 +322,16 @@ class RegPoints:
         eng.check(eng.fn("regpoints_create_dev")(C.c_int(device), C.c_void_p(ptr), C.c_uint64(n), C.byref(h)), "regpoints_create_dev")
         return cls._wrap(eng, h)
 
+    @classmethod
+    def from_isosurface(cls, eng, layer, min_weight=1.0, vertex_proximity_threshold=None):
+        """finishSubmap()'s isosurface vertices (the "explicit" set), built and kept on the engine's side."""
+        thr = 0.5 * layer.voxel_size if vertex_proximity_threshold is None else vertex_proximity_threshold
+        h, nm, nc = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        eng.check(eng.fn("regpoints_from_isosurface")(layer.h, C.c_float(min_weight), C.c_float(thr), C.byref(h), C.byref(nm), C.byref(nc)), "regpoints_from_isosurface")
+        self = cls._wrap(eng, h)
+        self.n_mesh_vertices, self.n_connected_vertices = int(nm.value), int(nc.value)
+        return self
+
     def clone_to_device(self, device):
         h = C.c_void_p()
         self.eng.check(self.eng.fn("regpoints_clone_to_device")(self.h, C.c_int(device), C.byref(h)), "regpoints_clone_to_device")
@@ -383,6 +418,20 @@ class Registration:
         si = np.ascontiguousarray(sample_idx, np.uint32)
         self.eng.check(self.eng.fn("reg_set_samples")(self.h, _fp(si), C.c_uint64(si.shape[0])), "reg_set_samples")
         self.stored_n = int(si.shape[0])
+
+    def draw_samples(self, n_res, seed):
+        """The weighted sampler's draws for one evaluation, made on the engine's side; they become the stored set."""
+        self.eng.check(self.eng.fn("reg_draw_samples")(self.h, C.c_uint64(n_res), C.c_uint64(seed)), "reg_draw_samples")
+        self.stored_n = int(n_res)
+
+    def get_samples(self):
+        n = C.c_uint64()
+        f = self.eng.fn("reg_get_samples")
+        self.eng.check(f(self.h, None, C.c_uint64(0), C.byref(n)), "reg_get_samples")
+        out = np.zeros(int(n.value), np.uint32)
+        if n.value:
+            self.eng.check(f(self.h, _fp(out), C.c_uint64(n.value), C.byref(n)), "reg_get_samples")
+        return out
 
     def normal_eq_begin(self, pose_ref, pose_read, sample_idx=None):
         pr, pd, si, n = self._args(pose_ref, pose_read, sample_idx)

@@ -76,6 +76,8 @@ struct cox_regpoints {
   int device = 0;
   float* pts = nullptr;  // n * {x, y, z, distance, weight}
   u64 n = 0;
+  u64* cum = nullptr;    // inclusive prefix sums of the fixed-point weights (built on first use by the weighted sampler)
+  u64 cum_total = 0;
 };
 
 // hipGetLastError() is a per-thread sticky slot shared with every other HIP user in the process

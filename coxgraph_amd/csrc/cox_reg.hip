@@ -277,6 +277,67 @@ __global__ void __launch_bounds__(256) k_reg_reduce_partials(const double* __res
   out[threadIdx.x] = s;
 }
 
+// ---- WeightedSampler<RegistrationPoint>::getRandomItem, reproducible and on the device ---------------------------------
+// voxgraph draws the registration points of an evaluation with replacement, proportionally to their weight (uniform in
+// [0, sum w), upper_bound on the cumulative weights, unseeded std::mt19937).  Here: weights in fixed point (2^-20 units ->
+// exact integer prefix sums whatever the order they are added in), draw i = splitmix64(seed, i) scaled to [0, total).
+__device__ __forceinline__ u64 weight_fixed(float w) {
+  if (!(w > 0.0f)) return 0;
+  const double s = static_cast<double>(w) * 1048576.0;
+  return s >= 1.8e19 ? ~0ull : static_cast<u64>(s);
+}
+// one workgroup: inclusive prefix sums of n fixed-point weights (a point set is built once per submap; n ~ 1e4..1e6)
+__global__ void __launch_bounds__(1024) k_weight_cumsum(const float* __restrict__ pts, u64 n, u64* __restrict__ cum, u64* __restrict__ total) {
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry_s;
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (u64 base = 0; base < n; base += 1024) {
+    const u64 i = base + threadIdx.x;
+    u64 v = (i < n) ? weight_fixed(pts[5 * i + 4]) : 0ull;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const u64 o = __shfl_up(v, off, 64);
+      if (lane >= static_cast<u32>(off)) v += o;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    u64 below = carry_s;
+    for (u32 w = 0; w < wave; ++w) below += wsum[w];
+    if (i < n) cum[i] = below + v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = below + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(256) k_draw_samples(const u64* __restrict__ cum, u64 n, u64 total, u64 seed, u32* __restrict__ out, u64 n_res) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_res) return;
+  if (total == 0) {
+    out[i] = 0;
+    return;
+  }
+  const u64 r = splitmix64(seed * 0x9E3779B97F4A7C15ull + i);
+  const u64 u = __umul64hi(r, total);  // uniform in [0, total)
+  u64 lo = 0, hi = n;                  // upper_bound: first index with cum > u
+  while (lo < hi) {
+    const u64 mid = (lo + hi) >> 1;
+    if (cum[mid] > u)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  out[i] = static_cast<u32>(lo);
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------
 struct cox_reg {
   const cox_regpoints* ref = nullptr;
@@ -441,6 +502,7 @@ void cox_regpoints_destroy(cox_regpoints_t* R) {
   if (!R) return;
   (void)hipSetDevice(R->device);
   if (R->pts) (void)hipFree(R->pts);
+  if (R->cum) (void)hipFree(R->cum);
   delete R;
 }
 
@@ -530,6 +592,42 @@ int cox_reg_set_samples(cox_reg_t* G, const uint32_t* sample_idx, uint64_t n_res
   COX_HIP(hipMemcpy(G->d_stored, sample_idx, sizeof(u32) * n_res, hipMemcpyHostToDevice));
   G->has_stored = true;
   G->stored_samples = n_res;
+  return COX_OK;
+}
+
+int cox_reg_draw_samples(cox_reg_t* G, uint64_t n_res, uint64_t seed) {
+  COX_ENTRY();
+  if (!G || n_res > 0x7FFFFFFFull || G->pending) return COX_ERR_INVALID_ARG;
+  cox_regpoints* R = const_cast<cox_regpoints*>(G->ref);
+  COX_HIP(hipSetDevice(R->device));
+  G->has_stored = false;
+  G->stored_samples = 0;
+  if (R->n == 0) return n_res == 0 ? COX_OK : COX_ERR_INVALID_ARG;
+  hipStream_t s = G->stream;
+  if (!R->cum) {
+    u64* cum = nullptr;
+    COX_HIP(hipMalloc(reinterpret_cast<void**>(&cum), sizeof(u64) * (R->n + 1)));
+    hipLaunchKernelGGL(k_weight_cumsum, dim3(1), dim3(1024), 0, s, R->pts, R->n, cum, cum + R->n);
+    COX_HIP(hipMemcpyAsync(&R->cum_total, cum + R->n, sizeof(u64), hipMemcpyDeviceToHost, s));
+    COX_HIP(hipStreamSynchronize(s));
+    R->cum = cum;
+  }
+  COX_TRY(dev_grow(&G->d_stored, &G->stored_cap, std::max<uint64_t>(n_res, 1)));
+  if (n_res) hipLaunchKernelGGL(k_draw_samples, dim3(static_cast<u32>((n_res + 255) / 256)), dim3(256), 0, s, R->cum, R->n, R->cum_total, seed, G->d_stored, n_res);
+  COX_HIP(hipGetLastError());
+  G->has_stored = true;
+  G->stored_samples = n_res;
+  return COX_OK;
+}
+int cox_reg_get_samples(cox_reg_t* G, uint32_t* sample_idx, uint64_t cap, uint64_t* n_res) {
+  COX_ENTRY();
+  if (!G || !n_res) return COX_ERR_INVALID_ARG;
+  *n_res = G->has_stored ? G->stored_samples : 0;
+  if (!sample_idx || !G->has_stored) return COX_OK;
+  if (cap < G->stored_samples) return COX_ERR_BUFFER_TOO_SMALL;
+  COX_HIP(hipSetDevice(G->reading->device));
+  COX_HIP(hipStreamSynchronize(G->stream));
+  if (G->stored_samples) COX_HIP(hipMemcpy(sample_idx, G->d_stored, sizeof(u32) * G->stored_samples, hipMemcpyDeviceToHost));
   return COX_OK;
 }
 

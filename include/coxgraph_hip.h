@@ -212,6 +212,31 @@ int cox_regpoints_clone_to_device(const cox_regpoints_t* src, int dst_device, co
 int cox_layer_registration_points(cox_layer_t* layer, float min_voxel_weight, float max_voxel_distance, float* out_xyz_dist_weight, uint64_t cap,
                                   uint64_t* n);
 int cox_regpoints_from_layer(cox_layer_t* layer, float min_voxel_weight, float max_voxel_distance, cox_regpoints_t** out);
+/* VoxgraphSubmap::finishSubmap() -> findIsosurfaceVertices (utils/msg_converter.h:113; the set the server's configured
+ * registration_method "explicit_to_implicit" uses, config/server.yaml:28-31): marching cubes over every block
+ * (voxblox MeshIntegrator, corners with weight <= min_weight invalidate a cube), vertices closer than
+ * vertex_proximity_threshold merged (createConnectedMesh; voxgraph passes half a voxel), TSDF distance and weight
+ * interpolated at every vertex (vertices without 8 observed neighbours dropped).  Order: blocks by (z,y,x), upstream's cube
+ * order inside a block.  n_mesh_vertices / n_connected_vertices (optional) report the raw and the merged vertex counts. */
+int cox_regpoints_from_isosurface(cox_layer_t* layer, float min_weight, float vertex_proximity_threshold, cox_regpoints_t** out, uint64_t* n_mesh_vertices,
+                                  uint64_t* n_connected_vertices);
+/* VoxgraphSubmap::getSubmapFrameSurfaceObb: box (submap frame) of the observed voxels (weight > 1e-6) within one voxel of the
+ * surface, grown by half a voxel; +-inf when there is none.  overlapsWith() -- the test behind
+ * updateRegistrationConstraints(), src/server/pose_graph_interface.cpp:38 -- compares the boxes' world-frame AABBs. */
+int cox_layer_surface_obb(cox_layer_t* layer, float min_xyz[3], float max_xyz[3], uint64_t* n_surface_voxels);
+/* voxblox EsdfIntegrator::Config (esdf_max_distance / esdf_min_distance: config/coxgraph_client.yaml:68-69) */
+typedef struct cox_esdf_config {
+  float max_distance_m;     /* the wavefront stops here */
+  float min_distance_m;     /* TSDF voxels closer than this to the surface are copied ("fixed") and seed the wavefront */
+  float default_distance_m; /* observed voxels start at +- this */
+  float min_weight;         /* TSDF voxels below this weight are unobserved */
+} cox_esdf_config;
+void cox_esdf_config_default(cox_esdf_config* cfg);
+/* VoxgraphSubmap::finishSubmap() -> generateEsdf (EsdfIntegrator::updateFromTsdfLayerBatch): the reading side of a
+ * registration constraint interpolates the ESDF when use_esdf_distance is set (voxgraph's default).  The result is a layer of
+ * its own in TSDF wire layout -- distance = ESDF distance, weight = 1 for observed voxels, colour word = 1 for fixed voxels --
+ * so it can be the `reading` of cox_reg_create, be downloaded or handed to another GPU like any layer. */
+int cox_esdf_from_tsdf(const cox_layer_t* tsdf, const cox_esdf_config* cfg, cox_layer_t** esdf_out);
 /* number of points in a set */
 int cox_regpoints_size(const cox_regpoints_t* pts, uint64_t* n);
 /* RegistrationConstraint::Config{first_submap_ptr, second_submap_ptr, registration{...}} as set up
@@ -240,6 +265,13 @@ int cox_reg_normal_eq_finish(cox_reg_t* reg, double H[64], double b[8], double* 
 /* Keep a set of sample indices on the GPU: later calls that pass sample_idx = NULL with this n_res use them (no 4*n_res
  * byte upload per evaluation).  sample_idx = NULL here drops the stored set (NULL then means "all points in order" again). */
 int cox_reg_set_samples(cox_reg_t* reg, const uint32_t* sample_idx, uint64_t n_res);
+/* WeightedSampler<RegistrationPoint>::getRandomItem for a whole evaluation, on the GPU: voxgraph's cost function draws its
+ * n_res = sampling_ratio * |set| points with replacement, weight-proportionally, with an unseeded std::mt19937 (not
+ * reproducible); here draw i = splitmix64(seed, i) scaled into the exact fixed-point prefix sums of the weights.  The draws
+ * become the stored set (as after cox_reg_set_samples); a caller that wants voxgraph's "fresh draw per Evaluate" passes a
+ * new seed before each evaluation.  cox_reg_get_samples copies the stored set to the host. */
+int cox_reg_draw_samples(cox_reg_t* reg, uint64_t n_res, uint64_t seed);
+int cox_reg_get_samples(cox_reg_t* reg, uint32_t* sample_idx, uint64_t cap, uint64_t* n_res);
 /* HIP-event time of the registration kernel since last reset (bench.py) */
 int cox_reg_kernel_time(cox_reg_t* reg, double* ms, uint64_t* launches, int reset);
 

@@ -6,6 +6,7 @@
 #include "../include/coxgraph_hip.h"
 #include "cox_oracle.hpp"
 #include "cox_oracle_mesh.hpp"
+#include "cox_oracle_submap.hpp"
 
 #include <map>
 #include <tuple>
@@ -551,6 +552,66 @@ int coxo_regpoints_clone_to_device(const coxo_regpoints* src, int, coxo_regpoint
   auto* h = new coxo_regpoints();
   h->pts = src->pts;
   *out = h;
+  return COX_OK;
+}
+}  // extern "C"
+
+// ---- finishSubmap(): surface box, isosurface registration points, ESDF, reproducible weighted sampler -----------------
+extern "C" {
+void coxo_esdf_config_default(cox_esdf_config* c) {
+  const EsdfConfig d;
+  c->max_distance_m = d.max_distance_m;
+  c->min_distance_m = d.min_distance_m;
+  c->default_distance_m = d.default_distance_m;
+  c->min_weight = d.min_weight;
+}
+int coxo_layer_surface_obb(coxo_layer* l, float mn[3], float mx[3], uint64_t* n) {
+  if (!l || !mn || !mx) return COX_ERR_INVALID_ARG;
+  const Box b = surfaceObb(l->layer);
+  for (int k = 0; k < 3; ++k) {
+    mn[k] = b.min[k];
+    mx[k] = b.max[k];
+  }
+  if (n) *n = b.count;
+  return COX_OK;
+}
+int coxo_regpoints_from_isosurface(coxo_layer* l, float min_weight, float threshold, coxo_regpoints** out, uint64_t* n_mesh, uint64_t* n_connected) {
+  if (!l || !out || !(threshold > 0.0f)) return COX_ERR_INVALID_ARG;
+  auto* h = new coxo_regpoints();
+  IsoStats st;
+  h->pts = isosurfacePoints(l->layer, min_weight, threshold, &st);
+  if (n_mesh) *n_mesh = st.n_mesh_vertices;
+  if (n_connected) *n_connected = st.n_connected;
+  *out = h;
+  return COX_OK;
+}
+int coxo_esdf_from_tsdf(const coxo_layer* tsdf, const cox_esdf_config* cfg, coxo_layer** out) {
+  if (!tsdf || !out) return COX_ERR_INVALID_ARG;
+  EsdfConfig c;
+  if (cfg) {
+    c.max_distance_m = cfg->max_distance_m;
+    c.min_distance_m = cfg->min_distance_m;
+    c.default_distance_m = cfg->default_distance_m;
+    c.min_weight = cfg->min_weight;
+  }
+  auto* e = new coxo_layer(tsdf->layer.voxel_size, tsdf->layer.vps);
+  esdfFromTsdf(tsdf->layer, c, &e->layer);
+  *out = e;
+  return COX_OK;
+}
+int coxo_reg_draw_samples(coxo_reg* reg, uint64_t n_res, uint64_t seed) {
+  if (!reg || reg->pending) return COX_ERR_INVALID_ARG;
+  if (reg->ref->pts.empty()) return n_res == 0 ? COX_OK : COX_ERR_INVALID_ARG;
+  reg->stored = drawWeightedSamples(reg->ref->pts, n_res, seed);
+  reg->has_stored = true;
+  return COX_OK;
+}
+int coxo_reg_get_samples(coxo_reg* reg, uint32_t* out, uint64_t cap, uint64_t* n) {
+  if (!reg || !n) return COX_ERR_INVALID_ARG;
+  *n = reg->has_stored ? reg->stored.size() : 0;
+  if (!out || !reg->has_stored) return COX_OK;
+  if (cap < reg->stored.size()) return COX_ERR_BUFFER_TOO_SMALL;
+  std::copy(reg->stored.begin(), reg->stored.end(), out);
   return COX_OK;
 }
 }  // extern "C"
