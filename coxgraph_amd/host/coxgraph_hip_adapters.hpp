@@ -56,6 +56,10 @@ class TsdfLayer {
   TsdfLayer(float voxel_size, size_t voxels_per_side = 16, int device = 0, uint64_t capacity_blocks = 0) : voxel_size_(voxel_size), vps_(voxels_per_side) {
     check(cox_layer_create(voxel_size, static_cast<int>(voxels_per_side), device, capacity_blocks, &h_), "Layer");
   }
+  // an exact copy of `other` on `device` (the submap hand-over: block array + keys GPU to GPU, hash rebuilt there)
+  TsdfLayer(const TsdfLayer& other, int device) : voxel_size_(other.voxel_size_), vps_(other.vps_) {
+    check(cox_layer_clone_to_device(other.h_, device, 0, &h_), "Layer(copy)");
+  }
   ~TsdfLayer() { cox_layer_destroy(h_); }
   TsdfLayer(const TsdfLayer&) = delete;
   TsdfLayer& operator=(const TsdfLayer&) = delete;
@@ -309,15 +313,37 @@ class RegistrationCostFunction {
     cox_reg_config cfg{no_correspondence_cost};
     check(cox_reg_create(pts_, reading_layer.handle(), &cfg, &reg_), "RegistrationCostFunction");
   }
+  // reference points and reading layer that already live on the GPU (a finished submap's sets): nothing is copied, the
+  // caller keeps both alive (`keepalive`: whatever owns them, typically the two submaps)
+  RegistrationCostFunction(cox_regpoints_t* reference_points, cox_layer_t* reading_layer, double no_correspondence_cost = 0.0,
+                           std::vector<std::shared_ptr<const void>> keepalive = std::vector<std::shared_ptr<const void>>())
+      : owns_points_(false), pts_(reference_points), keepalive_(std::move(keepalive)) {
+    uint64_t n = 0;
+    check(cox_regpoints_size(pts_, &n), "RegistrationCostFunction");
+    n_ = static_cast<size_t>(n);
+    cox_reg_config cfg{no_correspondence_cost};
+    check(cox_reg_create(pts_, reading_layer, &cfg, &reg_), "RegistrationCostFunction");
+  }
+  RegistrationCostFunction(const RegistrationCostFunction&) = delete;
+  RegistrationCostFunction& operator=(const RegistrationCostFunction&) = delete;
   ~RegistrationCostFunction() {
     cox_reg_destroy(reg_);
-    cox_regpoints_destroy(pts_);
+    if (owns_points_) cox_regpoints_destroy(pts_);
   }
-  int num_residuals() const { return static_cast<int>(sample_idx_.empty() ? n_ : sample_idx_.size()); }
+  int num_residuals() const { return static_cast<int>(drawn_ ? drawn_ : (sample_idx_.empty() ? n_ : sample_idx_.size())); }
+  size_t num_points() const { return n_; }
+  // WeightedSampler::getRandomItem for a whole evaluation, on the GPU: n draws with replacement, weight-proportional,
+  // reproducible from the seed (they stay on the GPU and are used until the next draw / setSampleIndices)
+  void drawSamples(uint64_t n, uint64_t seed) {
+    check(cox_reg_draw_samples(reg_, n, seed), "drawSamples");
+    sample_idx_.clear();
+    drawn_ = static_cast<size_t>(n);
+  }
   // the weighted sampler's draws (sampling_ratio > 0); empty = every point once (sampling_ratio = -1)
   // (the indices are uploaded once and stay on the GPU)
   void setSampleIndices(const std::vector<uint32_t>& idx) {
     sample_idx_ = idx;
+    drawn_ = 0;
     check(cox_reg_set_samples(reg_, idx.empty() ? nullptr : idx.data(), idx.size()), "setSampleIndices");
   }
   // ceres::CostFunction::Evaluate: parameters = {reference pose (x,y,z,yaw), reading pose}, jacobians row-major N x 4
@@ -334,10 +360,13 @@ class RegistrationCostFunction {
   bool FinishNormalEquations(double H[64], double b[8], double* cost) const { return cox_reg_normal_eq_finish(reg_, H, b, cost, nullptr) == COX_OK; }
 
  private:
-  size_t n_;
+  size_t n_ = 0;
+  bool owns_points_ = true;
   cox_regpoints_t* pts_ = nullptr;
   cox_reg_t* reg_ = nullptr;
   std::vector<uint32_t> sample_idx_;
+  size_t drawn_ = 0;
+  std::vector<std::shared_ptr<const void>> keepalive_;
 };
 
 }  // namespace coxgraph_hip

@@ -19,7 +19,9 @@
 #include <set>
 #include <vector>
 
-#include "coxgraph_hip_adapters.hpp"
+#include <cstdio>
+
+#include "coxgraph_hip_submap.hpp"
 
 namespace coxgraph_hip {
 
@@ -118,7 +120,9 @@ struct RelativePoseConstraint {
 // RegistrationCostFunction per constraint (a handle has one evaluation in flight)
 struct RegistrationConstraint {
   int a = 0, b = 0;
-  RegistrationCostFunction* cost = nullptr;  // not owned
+  RegistrationCostFunction* cost = nullptr;          // the evaluator (== owned.get() when the pose graph built it itself)
+  std::shared_ptr<RegistrationCostFunction> owned;   // constraints created from the submap collection
+  double sampling_ratio = -1.0;                      // < 0: every point once; else int(ratio * |set|) weighted draws per solve
 };
 
 class PoseGraph {
@@ -130,7 +134,23 @@ class PoseGraph {
   std::map<int, Pose4> poses;
   std::set<int> constant;
   std::vector<RelativePoseConstraint> rel, submap_rel;  // submap_rel: consecutive-submap constraints, reset on every update
-  std::vector<RegistrationConstraint> reg;
+  std::vector<RegistrationConstraint> reg;        // forced registration constraints (addForceRegistrationConstraint): kept
+  std::vector<RegistrationConstraint> overlap_reg;  // overlap-driven ones: rebuilt by updateRegistrationConstraints()
+  uint64_t solve_counter = 0;                     // seeds the weighted sampler: fresh, reproducible draws per solve
+
+  void resetRegistrationConstraints() { overlap_reg.clear(); }
+  void resetSubmapRelativePoseConstraints() { submap_rel.clear(); }
+
+  // residual vectors of one class of relative-pose constraints at the current poses (4 numbers per constraint)
+  std::vector<double> evaluateResiduals(const std::vector<RelativePoseConstraint>& list) const {
+    std::vector<double> out;
+    for (const RelativePoseConstraint& c : list) {
+      double r[4], Ja[16], Jb[16];
+      c.evaluate(poses.at(c.a), poses.at(c.b), r, Ja, Jb);
+      out.insert(out.end(), r, r + 4);
+    }
+    return out;
+  }
 
   void addNode(int id, const Pose4& pose, bool is_constant = false) {
     poses[id] = pose;
@@ -171,9 +191,13 @@ class PoseGraph {
     };
     if (!exclude_registration) {
       // begin every constraint's evaluation, then collect: the kernels overlap, one latency round per evaluation of the graph
-      for (const RegistrationConstraint& c : reg)
-        if (!c.cost->BeginNormalEquations(P.at(c.a).v, P.at(c.b).v)) throw std::runtime_error("registration constraint: begin failed");
-      for (const RegistrationConstraint& c : reg) {
+      std::vector<const RegistrationConstraint*> all;
+      for (const RegistrationConstraint& c : reg) all.push_back(&c);
+      for (const RegistrationConstraint& c : overlap_reg) all.push_back(&c);
+      for (const RegistrationConstraint* cp : all)
+        if (!cp->cost->BeginNormalEquations(P.at(cp->a).v, P.at(cp->b).v)) throw std::runtime_error("registration constraint: begin failed");
+      for (const RegistrationConstraint* cp : all) {
+        const RegistrationConstraint& c = *cp;
         double H8[64], b8[8], ck = 0.0;
         if (!c.cost->FinishNormalEquations(H8, b8, &ck)) throw std::runtime_error("registration constraint: finish failed");
         double Haa[16], Hab[16], Hbb[16];
@@ -216,8 +240,17 @@ class PoseGraph {
   }
 
   // Levenberg-Marquardt with the Ceres parameter_tolerance test (backend/pose_graph.h:60)
-  Summary optimize(bool exclude_registration, int max_iterations = 50, double parameter_tolerance = 3e-3) {
+  Summary optimize(bool exclude_registration = false, int max_iterations = 50, double parameter_tolerance = 3e-3) {
     std::map<int, Pose4> P = poses;
+    if (!exclude_registration) {  // the sampler's draws of this solve (voxgraph redraws in every Evaluate; one set per solve keeps LM's cost comparisons meaningful)
+      ++solve_counter;
+      uint64_t k = 0;
+      for (auto* list : {&reg, &overlap_reg})
+        for (RegistrationConstraint& c : *list) {
+          ++k;
+          if (c.sampling_ratio >= 0.0) c.cost->drawSamples(static_cast<uint64_t>(c.sampling_ratio * static_cast<double>(c.cost->num_points())), solve_counter * 1000003ull + k);
+        }
+    }
     std::vector<double> g, H, g2, H2;
     std::vector<int> free_ids;
     double cost = build(P, exclude_registration, &g, &H, &free_ids);
@@ -299,10 +332,24 @@ class PoseGraph {
   }
 };
 
-// The facade coxgraph's server calls (coxgraph/include/coxgraph/server/pose_graph_interface.h:66-90)
+// The facade coxgraph's server calls (coxgraph/include/coxgraph/server/pose_graph_interface.h:19-108, the voxgraph base
+// class behind it, and their call sites: src/server/coxgraph_server.cpp:452,466,500,509,517,523,544-550,
+// src/server/visualizer/server_visualizer.cpp:28-56)
 class PoseGraphInterface {
  public:
-  PoseGraphInterface() {
+  enum class ConstraintType { RelPose, SubmapRelPose };  // printResiduals(ConstraintType), coxgraph_server.cpp:541-555
+  typedef std::map<int, Pose4> PoseMap;
+
+  // voxgraph's measurement_templates_.registration (config/server.yaml:28-36)
+  struct RegistrationConfig {
+    bool enabled = true;
+    double sampling_ratio = 0.3;
+    RegistrationPointType registration_point_type = RegistrationPointType::kIsosurfacePoints;  // "explicit_to_implicit"
+    bool use_esdf_distance = true;
+    double no_correspondence_cost = 0.0;
+  };
+
+  explicit PoseGraphInterface(SubmapCollection::Ptr submap_collection_ptr = SubmapCollection::Ptr()) : submap_collection_ptr_(std::move(submap_collection_ptr)) {
     // coxgraph/config/server.yaml:37-51
     const double lc[4] = {100.0, 100.0, 250.0, 250.0}, rp[4] = {1000.0, 1000.0, 2500.0, 2500.0};
     std::fill(lc_info_, lc_info_ + 16, 0.0);
@@ -312,45 +359,186 @@ class PoseGraphInterface {
       sm_rp_info_[5 * i] = rp[i];
     }
   }
-  // pose_graph_interface.cpp:10-30: submap 0 is constant
+  // copyable: the final-mesh service optimises a what-if copy while the live graph keeps running (pose_graph_interface.h:52-62,
+  // server_visualizer.cpp:28-31).  Constraints built from the collection get evaluators of their own (a handle has one
+  // evaluation in flight); evaluators handed in by the caller stay shared.
+  PoseGraphInterface(const PoseGraphInterface& rhs) { copyFrom(rhs, rhs.submap_collection_ptr_); }
+  PoseGraphInterface(const PoseGraphInterface& rhs, SubmapCollection::Ptr submap_collection_ptr) { copyFrom(rhs, std::move(submap_collection_ptr)); }
+  PoseGraphInterface& operator=(const PoseGraphInterface& rhs) {
+    if (this != &rhs) copyFrom(rhs, rhs.submap_collection_ptr_);
+    return *this;
+  }
+
+  void setVerbosity(bool verbose) { verbose_ = verbose; }
+  void setRegistrationConfig(const RegistrationConfig& c) { registration_ = c; }
+  const RegistrationConfig& getRegistrationConfig() const { return registration_; }
+  void setLoopClosureInformation(const double info[16]) { std::copy(info, info + 16, lc_info_); }
+  void setSubmapRelativePoseInformation(const double info[16]) { std::copy(info, info + 16, sm_rp_info_); }
+
+  // pose_graph_interface.cpp:10-30 (non-robocentric): the node's initial pose is the submap's pose in the collection,
+  // submap 0 is constant
+  void addSubmap(SubmapID submap_id) {
+    Transformation T;
+    if (!submap_collection_ptr_ || !submap_collection_ptr_->getSubmapPose(submap_id, &T)) throw std::runtime_error("addSubmap: submap not in the collection");
+    Pose4 p;
+    pose4FromTransformation(T, p.v);
+    clients_[static_cast<int>(submap_id)] = submap_collection_ptr_->getCliIdPairBySsid(submap_id).first;
+    pose_graph_.addNode(static_cast<int>(submap_id), p, submap_id == 0);
+  }
+  // without a collection: the pose and the client are given
   void addSubmap(int submap_id, const Pose4& pose, int client_id = 0) {
     clients_[submap_id] = client_id;
     pose_graph_.addNode(submap_id, pose, submap_id == 0);
   }
   bool addLoopClosureMeasurement(int a, int b, const double T_ab[4]) {
+    if (!pose_graph_.poses.count(a) || !pose_graph_.poses.count(b)) return false;
     pose_graph_.rel.emplace_back(a, b, T_ab, lc_info_);
     return true;
   }
-  // pose_graph_interface.cpp:88-105
-  void addForceRegistrationConstraint(int a, int b, RegistrationCostFunction* cost) { pose_graph_.reg.push_back(RegistrationConstraint{a, b, cost}); }
+  // addLoopClosureMeasurement(ser_sm_id_a, ser_sm_id_b, T_A_B, false)   (coxgraph_server.cpp:451-453)
+  bool addLoopClosureMeasurement(SubmapID a, SubmapID b, const Transformation& T_A_B, bool /*publish*/ = false) {
+    double t[4];
+    pose4FromTransformation(T_A_B, t);
+    return addLoopClosureMeasurement(static_cast<int>(a), static_cast<int>(b), t);
+  }
+  // pose_graph_interface.cpp:88-105: reference = first submap's registration points, reading = second submap's distance field
+  void addForceRegistrationConstraint(SubmapID a, SubmapID b) { pose_graph_.reg.push_back(makeRegistrationConstraint(a, b)); }
+  // with an evaluator of the caller's (not owned)
+  void addForceRegistrationConstraint(int a, int b, RegistrationCostFunction* cost) {
+    RegistrationConstraint c;
+    c.a = a, c.b = b, c.cost = cost;
+    pose_graph_.reg.push_back(c);
+  }
+  // voxgraph PoseGraphInterface::updateRegistrationConstraints (called at pose_graph_interface.cpp:38, between the two solves):
+  // drop the overlap-driven constraints of the previous round, then constrain every pair of submaps whose surface boxes
+  // overlap at the poses the first solve produced.  Forced constraints are a list of their own and stay.
+  void updateRegistrationConstraints() {
+    pose_graph_.resetRegistrationConstraints();
+    overlapping_submap_list_.clear();
+    if (!submap_collection_ptr_) return;
+    updateSubmapCollectionPoses();
+    const std::vector<SubmapID> ids = submap_collection_ptr_->getIDs();
+    for (size_t i = 0; i < ids.size(); ++i) {
+      if (!pose_graph_.poses.count(static_cast<int>(ids[i]))) continue;
+      const VoxgraphSubmap::ConstPtr first = submap_collection_ptr_->getSubmapConstPtr(ids[i]);
+      for (size_t j = i + 1; j < ids.size(); ++j) {
+        if (!pose_graph_.poses.count(static_cast<int>(ids[j]))) continue;
+        const VoxgraphSubmap::ConstPtr second = submap_collection_ptr_->getSubmapConstPtr(ids[j]);
+        if (first->isFinished() && second->isFinished() && first->overlapsWith(*second)) overlapping_submap_list_.emplace_back(ids[i], ids[j]);
+      }
+    }
+    for (const auto& pr : overlapping_submap_list_) pose_graph_.overlap_reg.push_back(makeRegistrationConstraint(pr.first, pr.second));
+  }
+  const std::vector<std::pair<SubmapID, SubmapID>>& getOverlappingSubmapList() const { return overlapping_submap_list_; }
+
+  void resetSubmapRelativePoseConstrains() { pose_graph_.resetSubmapRelativePoseConstraints(); }  // (sic) pose_graph_interface.h:72-74
   // pose_graph_interface.cpp:51-71: consecutive submaps of one client keep their current relative pose
   void updateSubmapRPConstraints() {
-    pose_graph_.submap_rel.clear();
+    resetSubmapRelativePoseConstrains();
     std::map<int, std::vector<int>> by_client;
-    for (const auto& kv : clients_) by_client[kv.second].push_back(kv.first);  // std::map: ids ascending
+    if (submap_collection_ptr_) {
+      for (int cid = 0; cid < submap_collection_ptr_->getClientNumber(); ++cid) {
+        std::vector<SubmapID> ids;
+        if (!submap_collection_ptr_->getSerSmIdsByCliId(cid, &ids)) continue;
+        for (SubmapID s : ids)
+          if (pose_graph_.poses.count(static_cast<int>(s))) by_client[cid].push_back(static_cast<int>(s));
+      }
+    } else {
+      for (const auto& kv : clients_) by_client[kv.second].push_back(kv.first);  // std::map: ids ascending
+    }
     for (const auto& kv : by_client)
       for (size_t k = 0; k + 1 < kv.second.size(); ++k) {
         const int i = kv.second[k], j = kv.second[k + 1];
-        const Pose4 &pa = pose_graph_.poses[i], &pb = pose_graph_.poses[j];
-        const double c = std::cos(pa.v[3]), s = std::sin(pa.v[3]);
-        const double d[3] = {pb.v[0] - pa.v[0], pb.v[1] - pa.v[1], pb.v[2] - pa.v[2]};
-        const double T_ij[4] = {c * d[0] + s * d[1], -s * d[0] + c * d[1], d[2], normalizeAngle(pb.v[3] - pa.v[3])};
-        pose_graph_.submap_rel.emplace_back(i, j, T_ij, sm_rp_info_);
+        double T_ij[4];
+        if (submap_collection_ptr_) {  // T_SMi_SMj = T_M_SMi^-1 * T_M_SMj from the collection's poses
+          const Transformation Ti = submap_collection_ptr_->getSubmapPtr(static_cast<SubmapID>(i))->getPose(), Tj = submap_collection_ptr_->getSubmapPtr(static_cast<SubmapID>(j))->getPose();
+          pose4FromTransformation(inverse(Ti) * Tj, T_ij);
+        } else {
+          const Pose4 &pa = pose_graph_.poses[i], &pb = pose_graph_.poses[j];
+          const double c = std::cos(pa.v[3]), s = std::sin(pa.v[3]);
+          const double d[3] = {pb.v[0] - pa.v[0], pb.v[1] - pa.v[1], pb.v[2] - pa.v[2]};
+          T_ij[0] = c * d[0] + s * d[1], T_ij[1] = -s * d[0] + c * d[1], T_ij[2] = d[2], T_ij[3] = normalizeAngle(pb.v[3] - pa.v[3]);
+        }
+        addSubmapRelativePoseConstraint(i, j, T_ij);
       }
   }
-  // pose_graph_interface.cpp:32-49: first without registration constraints, then with all constraints
+  void addSubmapRelativePoseConstraint(int first_submap_id, int second_submap_id, const double T_S1_S2[4]) {
+    pose_graph_.submap_rel.emplace_back(first_submap_id, second_submap_id, T_S1_S2, sm_rp_info_);
+  }
+  // The fork's check before a solve (coxgraph_server.cpp:509; implementation not in the reference tree): true when there
+  // is at least one loop-closure candidate between two known submaps.  The server only logs the outcome.
+  bool checkLoopClosureCandidates() const {
+    for (const RelativePoseConstraint& c : pose_graph_.rel)
+      if (pose_graph_.poses.count(c.a) && pose_graph_.poses.count(c.b)) return true;
+    return false;
+  }
+  // pose_graph_interface.cpp:32-49: solve without registration constraints; refresh the overlap-driven registration
+  // constraints at the loop-closed poses if enabled; solve with ALL constraints (forced registration constraints included,
+  // whatever the flag says)
   std::pair<PoseGraph::Summary, PoseGraph::Summary> optimize(bool enable_registration = true) {
     const PoseGraph::Summary first = pose_graph_.optimize(true);
-    const PoseGraph::Summary second = pose_graph_.optimize(!enable_registration);
+    if (enable_registration) updateRegistrationConstraints();
+    const PoseGraph::Summary second = pose_graph_.optimize(false);
     return {first, second};
   }
-  const std::map<int, Pose4>& getPoseMap() const { return pose_graph_.poses; }
+  const PoseMap& getPoseMap() const { return pose_graph_.poses; }
+  // the optimised node poses as transformations (yaw-only rotations: the 4-DoF pose graph drops roll and pitch)
+  std::map<SubmapID, Transformation> getSubmapPoses() const {
+    std::map<SubmapID, Transformation> out;
+    for (const auto& kv : pose_graph_.poses) out[static_cast<SubmapID>(kv.first)] = transformationFromPose4(kv.second.v);
+    return out;
+  }
+  // voxgraph PoseGraphInterface::updateSubmapCollectionPoses (server_visualizer.cpp:54): write the node poses back
+  void updateSubmapCollectionPoses() {
+    if (!submap_collection_ptr_) return;
+    for (const auto& kv : pose_graph_.poses)
+      if (submap_collection_ptr_->exists(static_cast<SubmapID>(kv.first))) submap_collection_ptr_->setSubmapPose(static_cast<SubmapID>(kv.first), transformationFromPose4(kv.second.v));
+  }
+  std::vector<double> evaluateResiduals(ConstraintType type) const {
+    return pose_graph_.evaluateResiduals(type == ConstraintType::RelPose ? pose_graph_.rel : pose_graph_.submap_rel);
+  }
+  void printResiduals(ConstraintType type) const {  // pose_graph_interface.h:85-90
+    for (double r : evaluateResiduals(type)) std::printf("%g ", r);
+    std::printf("\n");
+  }
   PoseGraph& poseGraph() { return pose_graph_; }
+  const SubmapCollection::Ptr& submapCollection() const { return submap_collection_ptr_; }
 
  private:
+  RegistrationConstraint makeRegistrationConstraint(SubmapID a, SubmapID b) const {
+    if (!submap_collection_ptr_) throw std::runtime_error("registration constraint: no submap collection");
+    const VoxgraphSubmap::ConstPtr first = submap_collection_ptr_->getSubmapConstPtr(a), second = submap_collection_ptr_->getSubmapConstPtr(b);
+    if (!first || !second) throw std::runtime_error("registration constraint: unknown submap");
+    const std::shared_ptr<RegistrationPointSet> pts = first->getRegistrationPoints(registration_.registration_point_type);
+    RegistrationConstraint c;
+    c.a = static_cast<int>(a), c.b = static_cast<int>(b);
+    c.owned.reset(new RegistrationCostFunction(pts->handle(), second->getReadingLayer(registration_.use_esdf_distance), registration_.no_correspondence_cost,
+                                               {std::shared_ptr<const void>(pts), std::shared_ptr<const void>(first), std::shared_ptr<const void>(second)}));
+    c.cost = c.owned.get();
+    c.sampling_ratio = registration_.sampling_ratio;
+    return c;
+  }
+  void copyFrom(const PoseGraphInterface& rhs, SubmapCollection::Ptr collection) {
+    pose_graph_ = rhs.pose_graph_;
+    clients_ = rhs.clients_;
+    std::copy(rhs.lc_info_, rhs.lc_info_ + 16, lc_info_);
+    std::copy(rhs.sm_rp_info_, rhs.sm_rp_info_ + 16, sm_rp_info_);
+    registration_ = rhs.registration_;
+    overlapping_submap_list_ = rhs.overlapping_submap_list_;
+    verbose_ = rhs.verbose_;
+    submap_collection_ptr_ = std::move(collection);
+    for (auto* list : {&pose_graph_.reg, &pose_graph_.overlap_reg})
+      for (RegistrationConstraint& c : *list)
+        if (c.owned) c = makeRegistrationConstraint(static_cast<SubmapID>(c.a), static_cast<SubmapID>(c.b));  // own evaluator, against the new collection's submaps
+  }
+
   PoseGraph pose_graph_;
+  SubmapCollection::Ptr submap_collection_ptr_;
   std::map<int, int> clients_;
   double lc_info_[16], sm_rp_info_[16];
+  RegistrationConfig registration_;
+  std::vector<std::pair<SubmapID, SubmapID>> overlapping_submap_list_;
+  bool verbose_ = false;
 };
 
 }  // namespace coxgraph_hip

@@ -83,7 +83,8 @@ class PoseGraph:
         self.constant = set()
         self.rel = []         # RelativePoseConstraint
         self.submap_rel = []  # consecutive-submap relative poses (reset every update, pose_graph_interface.cpp:51-71)
-        self.reg = []         # RegistrationConstraint
+        self.reg = []         # forced RegistrationConstraints (addForceRegistrationConstraint): kept
+        self.overlap_reg = []  # overlap-driven ones: rebuilt by updateRegistrationConstraints()
         self.last_summary = None
 
     # ---- nodes / constraints ---------------------------------------------------------------------------------
@@ -117,7 +118,8 @@ class PoseGraph:
                 H[4 * ib:4 * ib + 4, 4 * ia:4 * ia + 4] += Hab.T
 
         # registration constraints: dealt round-robin over ranks, summed with ONE all-reduce of a packed buffer
-        if not exclude_registration and self.reg:
+        all_reg = self.reg + self.overlap_reg
+        if not exclude_registration and all_reg:
             rank, world = (0, 1)
             if group is not None:
                 import torch.distributed as dist
@@ -127,7 +129,7 @@ class PoseGraph:
             cr = 0.0
             H_save, g_save = H, g
             H, g = Hr, gr
-            mine = [c for k, c in enumerate(self.reg) if k % world == rank]
+            mine = [c for k, c in enumerate(all_reg) if k % world == rank and c is not None]
             for c in mine:
                 c.begin(poses[c.a], poses[c.b])
             for c in mine:
@@ -197,7 +199,9 @@ class PoseGraphInterface:
         # coxgraph/config/server.yaml:37-51
         self.lc_info = np.diag([100.0, 100.0, 250.0, 250.0]) if loop_closure_information is None else loop_closure_information
         self.sm_rp_info = np.diag([1000.0, 1000.0, 2500.0, 2500.0]) if submap_relative_pose_information is None else submap_relative_pose_information
-        self.submaps = {}  # id -> dict(client, pose4, reg_points, layer)
+        self.submaps = {}  # id -> dict(client)
+        self.overlap_pairs = None        # callable(poses) -> [(a, b)]: which submaps' surface boxes overlap at these poses
+        self.constraint_factory = None   # callable(a, b) -> RegistrationConstraint for an overlapping pair
 
     def addSubmap(self, submap_id, pose4, client_id=0):
         """pose_graph_interface.cpp:10-30: submap 0 is constant."""
@@ -226,10 +230,39 @@ class PoseGraphInterface:
                 T_ij = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], d[2], normalize_angle(pb[3] - pa[3])])
                 self.pose_graph.submap_rel.append(RelativePoseConstraint(i, j, T_ij, self.sm_rp_info))
 
+    def resetSubmapRelativePoseConstrains(self):
+        """(sic) pose_graph_interface.h:72-74."""
+        self.pose_graph.submap_rel = []
+
+    def updateRegistrationConstraints(self):
+        """voxgraph PoseGraphInterface::updateRegistrationConstraints (called at pose_graph_interface.cpp:38): drop the
+        overlap-driven constraints, constrain every pair whose surface boxes overlap at the current poses.  The overlap test
+        and the constraint construction are callables set by the owner of the submaps (C++: coxgraph_hip_posegraph.hpp does
+        both itself from its SubmapCollection)."""
+        self.pose_graph.overlap_reg = []
+        if self.overlap_pairs is None or self.constraint_factory is None:
+            return
+        for a, b in self.overlap_pairs(self.getPoseMap()):
+            self.pose_graph.overlap_reg.append(self.constraint_factory(a, b))
+
+    def evaluateResiduals(self, constraint_type):
+        """'RelPose' (loop closures) or 'SubmapRelPose' (consecutive submaps): the stacked residual vectors at the current poses."""
+        lst = self.pose_graph.rel if constraint_type == "RelPose" else self.pose_graph.submap_rel
+        out = []
+        for c in lst:
+            out.extend(c.evaluate(self.pose_graph.poses[c.a], self.pose_graph.poses[c.b])[0])
+        return np.array(out)
+
+    def checkLoopClosureCandidates(self):
+        return any(c.a in self.pose_graph.poses and c.b in self.pose_graph.poses for c in self.pose_graph.rel)
+
     def optimize(self, enable_registration=True, group=None):
-        """pose_graph_interface.cpp:32-49: first without registration constraints, then with all constraints."""
+        """pose_graph_interface.cpp:32-49: solve without registration constraints; refresh the overlap-driven ones if enabled;
+        solve with ALL constraints -- forced registration constraints included, whatever the flag says."""
         first = self.pose_graph.optimize(exclude_registration=True, group=group)
-        second = self.pose_graph.optimize(exclude_registration=not enable_registration, group=group)
+        if enable_registration:
+            self.updateRegistrationConstraints()
+        second = self.pose_graph.optimize(exclude_registration=False, group=group)
         return first, second
 
     def getPoseMap(self):

@@ -114,6 +114,40 @@ def test_registration_constraint_pulls_pose_onto_the_surface(oracle):
     assert abs(float(p1[:3] @ n)) < 2e-3  # the displacement along the normal is gone
 
 
+def test_forced_registration_constraint_is_optimised_whatever_the_flag(oracle):
+    """pose_graph_interface.cpp:32-41: the second solve always runs with all constraints; enable_registration only gates
+    updateRegistrationConstraints() (the overlap-driven constraints) between the two solves."""
+    layer, pts, n = corner_problem(oracle)
+    off = 0.08 * n
+    calls = []
+
+    def build(enable):
+        reg = Registration(oracle, RegPoints(oracle, pts), layer)
+        g = PoseGraphInterface()
+        g.addSubmap(0, [0, 0, 0, 0])
+        g.addSubmap(1, [off[0], off[1], off[2], 0.0])
+        g.addForceRegistrationConstraint(0, 1, reg)
+        g.pose_graph.rel.append(RelativePoseConstraint(0, 1, [off[0], off[1], off[2], 0.0], np.eye(4) * 1e-3))
+        g.overlap_pairs = lambda poses: calls.append(enable) or []
+        g.constraint_factory = lambda a, b: None
+        g.optimize(enable_registration=enable)
+        return g.getPoseMap()[1]
+
+    p_off, p_on = build(False), build(True)
+    assert abs(float(p_off[:3] @ n)) < 2e-3 and np.allclose(p_off, p_on)
+    assert calls == [True]   # the overlap refresh ran only where it was enabled
+    g = PoseGraphInterface()
+    g.addSubmap(0, [0, 0, 0, 0])
+    g.addSubmap(1, [1, 0, 0, 0], client_id=0)
+    g.addSubmap(2, [2, 0, 0, 0.1], client_id=0)
+    g.updateSubmapRPConstraints()
+    assert len(g.evaluateResiduals("SubmapRelPose")) == 8 and np.allclose(g.evaluateResiduals("SubmapRelPose"), 0)
+    g.resetSubmapRelativePoseConstrains()
+    assert len(g.evaluateResiduals("SubmapRelPose")) == 0 and not g.checkLoopClosureCandidates()
+    g.addLoopClosureMeasurement(0, 2, [2.1, 0, 0, 0.1])
+    assert g.checkLoopClosureCandidates() and abs(g.evaluateResiduals("RelPose")[0] - (-1.0)) < 1e-9   # sqrt(100) * (2.0 - 2.1)
+
+
 def test_cpp_adapters_compile_and_link_against_the_c_abi(hip, tmp_path):
     """The reference-shaped C++ wrappers (coxgraph_amd/host) build with -std=c++14 like the reference
     (coxgraph/CMakeLists.txt:4) and link against the shared library; without a GPU the program reports so."""
