@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: 640x480 depth frames/s fused into a 5 cm TSDF submap per MI355X
-(BASELINE.json configs[1]) + submap registrations/s, one coxgraph client per GPU.
+"""Headline benchmark: 640x480 depth frames/s fused into a 5 cm TSDF submap per MI355X (BASELINE.json configs[1]) +
+submap registrations/s, one coxgraph client per GPU.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one synthetic depth frame: integratePointCloud(T_G_C,
-points_C, colors) of 307 200 points into the client's submap layer, inputs already resident in HBM.
-For N > 1 the driver launches one rank per GPU (torch.distributed over RCCL); clients are independent
-(weak scaling, no data-path collective -- SURVEY.md section 8e); the only collective is the
-barrier/max-reduce of the timing harness.
+A "step" is one pass of the hot path over one synthetic depth frame: integratePointCloud(T_G_C, points_C, colors) of
+307 200 points into the client's submap layer, inputs already resident in HBM.  The reference configures two integrators on
+this path: `merged` (coxgraph_sim/launch/experiments/mav_3dplanning_2d3dhouse_two.launch:10) and `fast`
+(coxgraph/config/tsdf_server_euroc.yaml:6).  `value` is `merged` (as in round 1); `fast` is a first-class block of its own
+under `other_methods` (own roofline, same frames), and each method's GPU / CPU ratio is taken against the CPU restatement of
+THE SAME method at the reference's 8 integrator threads (`cpu_baseline` = fast, `cpu_baseline.same_method` = merged).
 
-One JSON line on rank 0.  `roofline` prices the dominant kernel against HBM peak using the ALGORITHMIC
-bytes of SURVEY.md section 8d (16 B per valid point + 24 B per touched voxel); `cpu_baseline` times
-the CPU restatement of the reference's configured integrator (fast, 8 threads) on a bounded sample of
-the same frames on this box's host cores.
+For N > 1 the driver launches one rank per GPU (torch.distributed over RCCL); clients are independent (weak scaling, no
+data-path collective -- SURVEY.md section 8e).  After the fusion timing the ranks run the server's inter-robot leg
+(configs[2] / [4]): every client finishes its submap on its own GPU (ESDF + isosurface points), the submaps are exchanged
+GPU to GPU (one all-gather of the wire arrays), every constraint (a, b) registers CLIENT a's points against CLIENT b's
+distance field, and the packed normal equations are summed with ONE all-reduce per pose-graph evaluation.
+
+One JSON line on rank 0.  `roofline` prices the longest kernel class of a frame against HBM peak with the ALGORITHMIC bytes
+of SURVEY.md section 8d (16 B per valid point + 24 B per touched voxel); `cpu_baseline` times the CPU restatement of the
+reference's configured integrator (fast, 8 threads) on a bounded sample of the same frames on this box's host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,7 +33,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+KERNELS_OF_CLASS = {
+    "merge": "k_bundle_merge", "apply": "k_apply_eval+k_apply_long", "bundle_hash": "fillBuffer+k_bundle_insert+k_bundle_keys",
+    "point_sort": "k_rs_hist/offsets/scatter<11> (points)", "touch_emit": "k_scan_small+k_touch*+k_emit*",
+    "record_sort": "k_rs_hist/offsets/scatter<12> (records)", "fast_start": "k_fast_points..k_fast_rays (+ point sort)",
+    "fast_visits": "k_fast_visits+visit sort+k_fast_inverse", "fast_sweeps": "k_fast_scan_tiles+k_fast_sweep (all sweeps of a frame)",
+}
 
 
 def parse():
@@ -34,15 +47,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)  # the 300-frame 30 Hz stream of SURVEY.md section 8d
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--method", default="merged", choices=["merged", "simple", "fast"])
+    ap.add_argument("--method", default="merged", choices=["merged", "fast", "simple"])
     ap.add_argument("--no-events", action="store_true", help="no HIP-event kernel timing inside the timed region")
-    ap.add_argument("--fast-frames", type=int, default=300, help="frames of the same stream also run through method 'fast' (0 = skip)")
+    ap.add_argument("--other-frames", type=int, default=300, help="frames of the same stream also run through the other method (0 = skip)")
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the CPU baseline sample (0 = skip); ~10 s of CPU work at the default")
     ap.add_argument("--reg-iters", type=int, default=50)
+    ap.add_argument("--pcie-frames", type=int, default=100, help="frames of the PCIe-inclusive legs (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--serial", action="store_true", help="sync after every frame (profiling aid: kernel times without cross-frame overlap)")
     return ap.parse_args()
+
+
+def respawn_per_gpu(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU (the same command the driver uses) before
+    anything touches the GPU, and leave with its exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(frames, voxel, n_frames, threads):
@@ -56,12 +83,12 @@ def cpu_baseline(frames, voxel, n_frames, threads):
         g.build_oracle()
     eng = Engine(lib, "coxo_")
     out = {}
-    for method, thr in (("fast", threads), ("merged", 1)):
+    for method, thr in (("fast", threads), ("merged", threads)):
         cfg = eng.default_config(integrator_threads=thr, **synth.integrator_overrides(voxel))
         layer = Layer(eng, voxel)
         integ = Integrator(eng, layer, cfg, method)
         eng.fn("integrator_set_count_touched")(integ.h, C.c_int(0))
-        nf = n_frames if method == "fast" else max(2, n_frames // 4)  # the single-threaded merged run is context, keep it short
+        nf = n_frames if method == "fast" else max(2, n_frames // 2)
         t0 = time.perf_counter()
         for (T, pts, rgba) in frames[:nf]:
             integ.integrate_points(T, pts, rgba)
@@ -70,11 +97,28 @@ def cpu_baseline(frames, voxel, n_frames, threads):
     return out
 
 
+def pmc_traffic(method):
+    """Whole-frame HBM traffic from the committed PMC passes of the same command (rocprofv3 cannot run inside this
+    process): sum over the kernels of (FETCH_SIZE + WRITE_SIZE per launch) x (launches per frame)."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{method}.json")
+    try:
+        pm = json.load(open(path))
+        return float(pm["bytes_per_frame"]), {"source": os.path.relpath(path, ROOT), "commit": pm.get("commit"), "frames": pm.get("frames"),
+                                              "note": pm.get("note")}
+    except Exception:
+        return None, {"source": None, "note": "no PMC summary committed for this method yet"}
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        respawn_per_gpu(args)
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={env_world}")
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -94,73 +138,84 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     local_rank = dev_index
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     import coxgraph_amd
     from coxgraph_amd import synth
-    from coxgraph_amd.capi import Layer, Integrator, RegPoints, Registration, words_to_fields
+    from coxgraph_amd.capi import Layer, Integrator, RegPoints, Registration
     eng = coxgraph_amd.load_engine()
 
     # ---- synthetic stream of this rank's client, resident in HBM before anything is timed ----------
     n_frames = args.warmup + args.steps
-    host_frames = []
-    dev_frames = []
+    host_frames, dev_frames = [], []
+    keep_host = max(args.cpu_frames, args.pcie_frames, 1)
     for t in range(n_frames):
-        T, pts, rgba, _ = synth.make_frame(t, client=rank, n_clients=max(world, 1))
-        if t < max(args.cpu_frames, 1):
-            host_frames.append((T, pts, rgba))
+        # one client per GPU; with several clients they stand 30 degrees apart on the camera circle, so that neighbouring
+        # clients' submaps overlap and the inter-robot constraints have correspondences
+        T, pts, rgba, depth = synth.make_frame(t, client=rank, n_clients=(12 if world > 1 else 1))
+        if t < keep_host:
+            host_frames.append((T, pts, rgba, depth))
         dev_frames.append((T, torch.from_numpy(pts).cuda(), torch.from_numpy(rgba).cuda(), pts.shape[0]))
     torch.cuda.synchronize()
-
     cfg = eng.default_config(**synth.integrator_overrides(args.voxel))
-    layer = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-    integ = Integrator(eng, layer, cfg, args.method)
 
-    def step(i):
-        T, xyz, rgba, n = dev_frames[i]
-        integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
-        if args.serial:
-            integ.sync()
+    def clock_ramp(method, seconds=0.3):
+        """Untimed extra frames on a scratch layer so that the timed region starts at running clocks (the reported `warmup`
+        frames still go through the measured layer)."""
+        scratch = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+        si = Integrator(eng, scratch, cfg, method)
+        t0 = time.perf_counter()
+        i = 0
+        while time.perf_counter() - t0 < seconds:
+            T, xyz, rgba, n = dev_frames[i % n_frames]
+            si.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+            i += 1
+            if i % 16 == 0:
+                si.sync()
+        si.sync()
 
-    # HIP events around the two candidate dominant kernels are recorded on the engine's own streams INSIDE the timed
-    # region, for every 4th frame (measured: every frame costs 6.6 % of the throughput, every 4th < 2 %); --no-events
-    # times the region without them
-    if not args.no_events:
-        integ.set_profiling(4)
-    for i in range(args.warmup):
-        step(i)
-    integ.sync()
-    integ.stage_times(reset=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_frames):
-        step(i)
-    integ.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    fps = world * args.steps / dt
-    live_times = integ.stage_times() if not args.no_events else None
+    def run_stream(method, steps, timed_events):
+        """warm-up + `steps` timed frames on a fresh layer; barrier + device sync on both sides, MAX over ranks."""
+        layer = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+        integ = Integrator(eng, layer, cfg, method)
+        if timed_events:
+            integ.set_profiling(1 if steps < 64 else 4)  # every frame of a short run, every 4th otherwise (< 2 % of the throughput)
+        clock_ramp(method)
+        for i in range(args.warmup):
+            T, xyz, rgba, n = dev_frames[i]
+            integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+        integ.sync()
+        integ.class_times(reset=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + steps):
+            T, xyz, rgba, n = dev_frames[i]
+            integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+            if args.serial:
+                integ.sync()
+        integ.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        live = integ.class_times() if timed_events else None
+        return layer, integ, dt, live
 
-    # ---- roofline of the dominant kernel ---------------------------------------------------------------------------
-    # durations: HIP events recorded inside the timed region above (frames overlap on two streams there, so a kernel's
-    # duration includes what the other stream's kernels take from it -- the same view rocprofv3 --kernel-trace has of
-    # this command).  Algorithmic bytes need per-frame counters, which only a synchronous pass can read: the same frames
-    # are run again, one in flight, on a fresh layer; that pass also gives the kernels' undisturbed durations.
-    roofline = None
-    stats_sum = dict(n_valid=0, n_touched_voxels=0, n_updates=0, n_rays=0)
-    stats_max = dict(max_bundle_points=0, max_voxel_updates=0)
-    if rank == 0 and not args.no_profile_pass:
+    def roofline_of(method, steps, live):
+        """Algorithmic bytes need per-frame counters, which only a synchronous pass can read: the same frames once more, one in
+        flight, on a fresh layer; that pass also gives the kernel classes' undisturbed durations."""
+        stats_sum = dict(n_valid=0, n_touched_voxels=0, n_updates=0, n_rays=0)
+        stats_max = dict(max_bundle_points=0, max_voxel_updates=0)
         layer2 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        integ2 = Integrator(eng, layer2, cfg, args.method)
+        integ2 = Integrator(eng, layer2, cfg, method)
         integ2.set_profiling(True)
-        for i in range(n_frames):
+        for i in range(args.warmup + steps):
             T, xyz, rgba, n = dev_frames[i]
             integ2.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
             integ2.sync()
@@ -171,51 +226,106 @@ def main():
                 for k in stats_max:
                     stats_max[k] = max(stats_max[k], st[k])
             elif i == args.warmup - 1:
-                integ2.stage_times(reset=True)
-        serial = integ2.stage_times()
-        st = live_times if live_times is not None else serial
+                integ2.class_times(reset=True)
+        serial = integ2.class_times()
+        st = live if live is not None else serial
+        per_frame = lambda d: {k: (v[0] / v[1] if v[1] else None) for k, v in d.items() if v[1]}
+        # a class may have several regions per frame (the fast integrator's rounds): price it per FRAME
+        frames_timed = max(st["apply"][1], 1)
+        per_frame_ms = {k: v[0] / frames_timed for k, v in st.items() if v[1]}
         # B_frame = 16 B per valid point + 24 B per touched voxel (12-B TsdfVoxel read + written)
-        alg_bytes = 16.0 * stats_sum["n_valid"] + 24.0 * stats_sum["n_touched_voxels"]
-        kernels = {"merge": "k_bundle_merge", "apply": "k_apply_eval+k_apply_long"}
-        stage = max(st, key=lambda k: st[k][0]) if args.method == "merged" else "apply"
-        ms, launches = st[stage]
-        if launches:
-            per_launch_bytes = alg_bytes / args.steps
-            avg_ms = ms / launches
-            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-            # HBM bytes per launch from the committed PMC passes (profiles/, same command with --serial): rocprofv3 cannot
-            # run inside this process, so the figure is read back from the summary it produced
-            traffic = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                names = kernels[stage].split("+")
-                traffic = sum(pm[k]["fetch_bytes"] + pm[k]["write_bytes"] for k in names)
-            except Exception:
-                traffic = None
-            avg = lambda d: {kernels[k]: (v[0] / v[1] if v[1] else None) for k, v in d.items()}
-            roofline = {"bound": "hbm", "kernel": kernels[stage], "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms,
-                        "algorithmic_bytes_per_launch": per_launch_bytes, "launches_timed": launches,
-                        "timing": "HIP events on the engine's streams inside the timed region, every 4th frame" if live_times is not None else "HIP events, one frame in flight",
-                        "note": "one launch = one frame; the path is bound by dependent in-order update chains, not by HBM, at 5 cm (DESIGN.md section 6)",
-                        "stage_avg_ms": avg(st), "stage_avg_ms_one_frame_in_flight": avg(serial),
-                        "updates_per_s_in_apply": (stats_sum["n_updates"] / args.steps) / (st["apply"][0] / st["apply"][1] * 1e-3) if st["apply"][1] else None}
-        del integ2, layer2
+        alg_bytes = (16.0 * stats_sum["n_valid"] + 24.0 * stats_sum["n_touched_voxels"]) / max(steps, 1)
+        dom = max(per_frame_ms, key=per_frame_ms.get)
+        ms = per_frame_ms[dom]
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(method)
+        roof = {"bound": "hbm", "kernel": KERNELS_OF_CLASS[dom], "kernel_class": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_ratio": (traffic / alg_bytes) if traffic else None,
+                "traffic_scope": "whole frame: sum over all kernels of (FETCH_SIZE + WRITE_SIZE) per launch x launches per frame", "traffic_source": src,
+                "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": frames_timed,
+                "launch_unit": "one frame's launches of this kernel class (HIP events around the class on its own stream)",
+                "timing": ("HIP events inside the timed region, every frame" if steps < 64 else "HIP events inside the timed region, every 4th frame") if live is not None
+                          else "HIP events, one frame in flight",
+                "class_ms_per_frame": per_frame_ms, "class_ms_per_frame_one_in_flight": {k: v[0] / max(serial["apply"][1], 1) for k, v in serial.items() if v[1]},
+                "whole_frame_algorithmic_GBps": None,
+                "note": "the path is bound by dependent in-order chains and launch latency, not by HBM, at 5 cm (DESIGN.md section 6)"}
+        fstats = {k: v / max(steps, 1) for k, v in stats_sum.items()}
+        return roof, fstats, stats_max, alg_bytes
 
-    # ---- registrations/s: one fused residual+Jacobian+normal-equation evaluation of one constraint ------
+    # ---- headline ----------------------------------------------------------------------------------------------------
+    layer, integ, dt, live = run_stream(args.method, args.steps, not args.no_events)
+    fps = world * args.steps / dt
+    roofline, frame_stats, crit, alg_bytes = (None, None, None, None)
+    if rank == 0 and not args.no_profile_pass:
+        roofline, frame_stats, crit, alg_bytes = roofline_of(args.method, args.steps, live)
+        roofline["whole_frame_algorithmic_GBps"] = alg_bytes / (dt / args.steps) / 1e9
+
+    # ---- the other method on the same stream, as a block of its own -------------------------------------------------------
+    other = None
+    if rank == 0 and world == 1 and args.other_frames > 0 and args.method in ("fast", "merged"):
+        om = "merged" if args.method == "fast" else "fast"
+        nf = min(args.other_frames, args.steps)
+        _, _, dto, liveo = run_stream(om, nf, not args.no_events)
+        ro, fso, co, ab = (None, None, None, None)
+        if not args.no_profile_pass:
+            ro, fso, co, ab = roofline_of(om, nf, liveo)
+            ro["whole_frame_algorithmic_GBps"] = ab / (dto / nf) / 1e9
+        other = {om: {"value": nf / dto, "unit": "frames/s", "frames": nf, "ms_per_step": dto / nf * 1e3, "roofline": ro, "frame_stats_mean": fso, "critical_path": co,
+                      "note": ("MergedTsdfIntegrator semantics" if om == "merged" else "FastTsdfIntegrator semantics at integrator_threads=1") +
+                              ", bit-exact vs the CPU oracle (DESIGN.md section 5)"}}
+
+    # ---- PCIe-inclusive: what the boundary costs when the caller hands over host buffers -----------------------------------
+    pcie = None
+    if rank == 0 and world == 1 and args.pcie_frames > 0:
+        nf = min(args.pcie_frames, len(host_frames))
+        lp = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+        ip = Integrator(eng, lp, cfg, args.method)
+        for T, p, c, _ in host_frames[:5]:
+            ip.integrate_points(T, p, c)
+        t0 = time.perf_counter()
+        for T, p, c, _ in host_frames[:nf]:
+            ip.integrate_points(T, p, c)  # cox_integrate_points: 4.9 MB H2D + frame + sync, one frame in flight
+        dt_pts = time.perf_counter() - t0
+        # depth images (1.2 MB + 1.2 MB colour) from pinned memory on the caller's own stream, ordered against the engine
+        # (cox_integrator_set_input_stream): the H2D copy of frame t+1 overlaps the kernels of frame t
+        ld = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+        idp = Integrator(eng, ld, cfg, args.method)
+        side = torch.cuda.Stream()
+        idp.set_input_stream(side.cuda_stream)
+        K = np.array(synth.INTRINSICS[(640, 480)], np.float32)
+        rgba_img = torch.from_numpy(synth.frame_colors()).pin_memory()
+        pinned = [torch.from_numpy(d).pin_memory() for _, _, _, d in host_frames[:nf]]
+        with torch.cuda.stream(side):
+            t0 = time.perf_counter()
+            for (T, _, _, _), hd in zip(host_frames[:nf], pinned):
+                dd = hd.to("cuda", non_blocking=True)
+                cc = rgba_img.to("cuda", non_blocking=True)
+                idp.integrate_depth_dev(T, dd.data_ptr(), cc.data_ptr(), 640, 480, K)
+            idp.sync()
+            dt_depth = time.perf_counter() - t0
+        pcie = {"method": args.method, "frames": nf,
+                "host_points_frames_per_s": nf / dt_pts, "host_points_bytes_per_frame": int(host_frames[0][1].nbytes + host_frames[0][2].nbytes),
+                "depth_image_frames_per_s": nf / dt_depth, "depth_image_bytes_per_frame": int(host_frames[0][3].nbytes + 640 * 480 * 4),
+                "note": "never `value`: host buffers through cox_integrate_points (synchronous, one frame in flight) and pinned depth + colour images "
+                        "through cox_integrate_depth_dev on the caller's stream"}
+        del ip, lp, idp, ld
+
+    # ---- registrations/s: the server's configured constraint (config/server.yaml:28-31): isosurface vertices of the reference
+    # submap against the ESDF of the reading submap, sampling_ratio 0.3 drawn by the weighted sampler on the GPU -------------
     reg = None
+    trunc = cfg.default_truncation_distance
+    esdf_cfg = dict(max_distance_m=2.0, min_distance_m=0.5 * trunc)
     if rank == 0 and args.reg_iters > 0:
         from coxgraph_amd.posegraph import PoseGraphInterface
-        trunc = cfg.default_truncation_distance
-        # finishSubmap()'s relevant-voxel point set, extracted and kept on the GPU; reading layer = the fused submap itself,
-        # displaced by the SURVEY.md section 8d perturbation
-        ref = RegPoints.from_layer(eng, layer, 1.0, trunc)
-        ww = layer.registration_points(1.0, trunc)[:, 4].astype(np.float64)
-        rng = np.random.default_rng(7)
-        n_res = int(0.3 * ref.n)  # sampling_ratio 0.3, coxgraph/config/server.yaml:30
-        sidx = rng.choice(ref.n, size=n_res, replace=True, p=ww / ww.sum()).astype(np.uint32)
-        g = Registration(eng, ref, layer)
+        t0 = time.perf_counter()
+        ref = RegPoints.from_isosurface(eng, layer, 1.0)
+        esdf = layer.esdf(**esdf_cfg)
+        finish_ms = (time.perf_counter() - t0) * 1e3
+        n_res = int(0.3 * ref.n)
+        g = Registration(eng, ref, esdf)
+        g.draw_samples(n_res, 7)
         pr, pd = np.zeros(4), np.array([0.05, -0.03, 0.02, np.radians(1.0)])
+
         def rate(fn, calls, per_call=1, reps=3):
             """median calls/s over `reps` timed repetitions (the first call of a loop pays clock ramp-up)"""
             fn()
@@ -226,58 +336,95 @@ def main():
                     fn()
                 out.append(per_call * calls / (time.perf_counter() - t1))
             return sorted(out)[len(out) // 2]
-        g.normal_eq(pr, pd, sidx)
+        g.normal_eq(pr, pd)
         g.kernel_time(reset=True)
-        one_at_a_time = rate(lambda: g.normal_eq(pr, pd, sidx), args.reg_iters)
+        one_at_a_time = rate(lambda: g.normal_eq(pr, pd), args.reg_iters)
         kms, kl = g.kernel_time()
-        # the server's pattern: one pose-graph evaluation begins all of its constraints, then collects them; sample
-        # indices stay on the GPU (8 constraints in flight: configs[4] has 28 inter-robot pairs over 8 ranks)
-        batch = [Registration(eng, ref, layer) for _ in range(8)]
-        for b in batch:
-            b.set_samples(sidx)
+        batch = [Registration(eng, ref, esdf) for _ in range(8)]
+        for k, b in enumerate(batch):
+            b.draw_samples(n_res, 100 + k)
+
         def evaluate_all():
             for b in batch:
                 b.normal_eq_begin(pr, pd)
             return [b.normal_eq_finish() for b in batch]
         in_flight = rate(evaluate_all, max(1, args.reg_iters // 8), per_call=8)
-        # full two-stage solve of a 2-node graph (loop closure + forced registration constraint), pose_graph_interface.cpp:32-49
         pg = PoseGraphInterface()
         pg.addSubmap(0, [0, 0, 0, 0])
         pg.addSubmap(1, pd)
         pg.addLoopClosureMeasurement(0, 1, [0.02, 0.0, -0.01, np.radians(0.5)])
-        pg.addForceRegistrationConstraint(0, 1, g, sidx)
+        pg.addForceRegistrationConstraint(0, 1, g)
         t2 = time.perf_counter()
         _, second = pg.optimize(enable_registration=True)
         solve_ms = (time.perf_counter() - t2) * 1e3
         reg = {"registrations_per_s": in_flight, "registrations_per_s_one_at_a_time": one_at_a_time, "residuals_per_registration": n_res, "registration_points": int(ref.n),
+               "point_set": "isosurface vertices (explicit_to_implicit), ESDF reading", "finish_submap_ms": finish_ms,
                "kernel_ms": kms / max(kl, 1), "kernel_GBps_algorithmic": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9,
-               "two_stage_solve_ms": solve_ms, "solve_evaluations": second["evaluations"],
-               "solved_pose_error": [float(x) for x in pg.getPoseMap()[1]]}
+               "roofline_frac": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "two_stage_solve_ms": solve_ms, "solve_evaluations": second["evaluations"], "solved_pose_error": [float(x) for x in pg.getPoseMap()[1]]}
 
-    # ---- N > 1: the server's inter-robot registration, constraints dealt over the ranks, one all-reduce per evaluation ----
-    # (SURVEY.md section 8e / BASELINE configs[2], [4]): all pairs of 8 submaps = 28 forced registration constraints; every
-    # rank evaluates its share against its own client's map (begin all, then collect) and the packed (4N)^2 + 4N + 1
-    # doubles are summed with ONE all-reduce (RCCL when the backend is nccl).  Max over ranks, like the fusion timing.
+    # ---- N > 1: submap exchange + inter-robot registration ------------------------------------------------------------------
     dist_reg = None
     if world > 1 and args.reg_iters > 0:
         from coxgraph_amd.posegraph import PoseGraph, RegistrationConstraint
-        trunc = cfg.default_truncation_distance
-        ref = RegPoints.from_layer(eng, layer, 1.0, trunc)
-        rng = np.random.default_rng(7 + rank)
-        n_res = int(0.3 * ref.n)
-        sidx = rng.integers(0, max(ref.n, 1), size=n_res).astype(np.uint32)
+        # finishSubmap() on the client's own GPU
+        ref = RegPoints.from_isosurface(eng, layer, 1.0)
+        esdf = layer.esdf(**esdf_cfg)
+        nb, npts = esdf.n_blocks(), ref.n
+        sizes = torch.tensor([nb, npts], dtype=torch.int64, device=coll_dev)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        all_sizes = [tuple(int(v) for v in t.tolist()) for t in all_sizes]
+        max_nb, max_np = max(s[0] for s in all_sizes), max(s[1] for s in all_sizes)
+        idx_t = torch.zeros((max_nb, 3), dtype=torch.int32, device="cuda")
+        vox_t = torch.zeros((max_nb, 4096, 3), dtype=torch.int32, device="cuda")
+        pts_t = torch.zeros((max_np, 5), dtype=torch.float32, device="cuda")
+        esdf.export_dev(idx_t.data_ptr(), vox_t.data_ptr(), max_nb)
+        pts_t[:npts].copy_(torch.from_numpy(ref.download()).cuda())  # preparation, not part of the timed exchange
+        torch.cuda.synchronize()
+        dist.barrier()
+        # the exchange: one all-gather of (block indices, voxel words, point sets); device to device over xGMI with RCCL
+        t0 = time.perf_counter()
+        if backend == "nccl":
+            g_idx = torch.empty((world, max_nb, 3), dtype=torch.int32, device="cuda")
+            g_vox = torch.empty((world, max_nb, 4096, 3), dtype=torch.int32, device="cuda")
+            g_pts = torch.empty((world, max_np, 5), dtype=torch.float32, device="cuda")
+            dist.all_gather_into_tensor(g_idx, idx_t)
+            dist.all_gather_into_tensor(g_vox, vox_t)
+            dist.all_gather_into_tensor(g_pts, pts_t)
+        else:  # rehearsal over gloo: through the host
+            def gather(t):
+                lst = [torch.empty_like(t, device="cpu") for _ in range(world)]
+                dist.all_gather(lst, t.cpu())
+                return torch.stack(lst).cuda()
+            g_idx, g_vox, g_pts = gather(idx_t), gather(vox_t), gather(pts_t)
+        torch.cuda.synchronize()
+        dt_x = time.perf_counter() - t0
+        tt = torch.tensor([dt_x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_x = float(tt.item())
+        recv_bytes = sum((s[0] * (12 + 49152) + s[1] * 20) for k, s in enumerate(all_sizes) if k != rank)
+        # constraints (a, b), a < b: CLIENT a's isosurface points against CLIENT b's ESDF, dealt over the ranks
+        pairs = [(a, b) for a in range(world) for b in range(a + 1, world)]
         pg = PoseGraph()
-        n_nodes = 8
-        for k in range(n_nodes):
+        for k in range(world):
             pg.add_node(k, [0.01 * k, -0.005 * k, 0.002 * k, 0.001 * k], constant=(k == 0))
-        pairs = [(a, b) for a in range(n_nodes) for b in range(a + 1, n_nodes)]
+        layers, points = {}, {}
+        n_corr_total = 0
         for k, (a, b) in enumerate(pairs):
-            if k % world == rank:
-                g = Registration(eng, ref, layer)
-                g.set_samples(sidx)
-                pg.reg.append(RegistrationConstraint(a, b, g))
-            else:
+            if k % world != rank:
                 pg.reg.append(None)  # another rank's constraint: never touched here
+                continue
+            if b not in layers:
+                lb = Layer(eng, args.voxel, device=local_rank, capacity_blocks=max(64, all_sizes[b][0]))
+                lb.upload_dev(g_idx[b].data_ptr(), g_vox[b].data_ptr(), all_sizes[b][0])
+                layers[b] = lb
+            if a not in points:
+                points[a] = RegPoints.from_device(eng, g_pts[a].data_ptr(), all_sizes[a][1], device=local_rank)
+            gab = Registration(eng, points[a], layers[b])
+            gab.draw_samples(int(0.3 * points[a].n), 1000 + k)
+            n_corr_total += gab.normal_eq(pg.poses[a], pg.poses[b])[3]
+            pg.reg.append(RegistrationConstraint(a, b, gab))
         poses = {k: v.copy() for k, v in pg.poses.items()}
         pg.build(poses, group=dist.group.WORLD)
         dist.barrier()
@@ -288,42 +435,27 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         dt4 = time.perf_counter() - t4
-        tt = torch.tensor([dt4], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt4 = float(tt.item())
+        tt = torch.tensor([dt4, float(n_corr_total)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+        dt4 = float(tt[0].item())
         dist_reg = {"pose_graph_evaluations_per_s": n_eval / dt4, "registrations_per_s": n_eval * len(pairs) / dt4, "constraints": len(pairs),
-                    "residuals_per_constraint": n_res, "all_reduce_doubles": (4 * (n_nodes - 1)) ** 2 + 4 * (n_nodes - 1) + 1,
-                    "backend": "rccl" if backend == "nccl" else backend, "cost": cost}
-
-    # ---- the reference's configured method (`method: "fast"`, tsdf_server_euroc.yaml:6) on the same stream, for context ----
-    other = None
-    if rank == 0 and world == 1 and args.method != "fast" and args.fast_frames > 0:
-        nf = min(args.fast_frames, args.steps)  # the same frames as the headline number: warm-up frames first, untimed
-        layer3 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        integ3 = Integrator(eng, layer3, cfg, "fast")
-        for i in range(args.warmup):
-            T, xyz, rgba, n = dev_frames[i]
-            integ3.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
-        integ3.sync()
-        t3 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + nf):
-            T, xyz, rgba, n = dev_frames[i]
-            integ3.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
-        integ3.sync()
-        dt3 = time.perf_counter() - t3
-        other = {"fast": {"value": nf / dt3, "unit": "frames/s", "frames": nf,
-                          "note": "FastTsdfIntegrator semantics at integrator_threads=1, bit-exact vs the CPU oracle (DESIGN.md section 5c)"}}
-        del integ3, layer3
+                    "constraint": "client a's isosurface points against client b's ESDF (a < b), after the exchange",
+                    "correspondences_over_all_constraints": int(tt[1].item()),
+                    "submap_exchange_ms": dt_x * 1e3, "submap_exchange_GBps": recv_bytes / dt_x / 1e9, "submap_exchange_bytes_received_per_rank": recv_bytes,
+                    "submap_blocks": [s[0] for s in all_sizes], "isosurface_points": [s[1] for s in all_sizes],
+                    "all_reduce_doubles": (4 * (world - 1)) ** 2 + 4 * (world - 1) + 1, "backend": "rccl" if backend == "nccl" else backend, "cost": cost}
 
     # ---- CPU baseline on rank 0, N = 1 only ---------------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         threads = min(8, os.cpu_count() or 1)
-        res = cpu_baseline(host_frames, args.voxel, min(args.cpu_frames, len(host_frames)), threads)
+        res = cpu_baseline([f[:3] for f in host_frames], args.voxel, min(args.cpu_frames, len(host_frames)), threads)
         cpu = {"value": res["fast"][0], "unit": "frames/s", "cores": threads, "kind": "port",
-               "sample": f"oracle FastTsdfIntegrator restatement, {threads} threads (reference integrator_threads: 8), first {res['fast'][1]} frames of the "
-                         f"same stream, {res['fast'][2]:.1f} s; oracle merged 1 thread: {res['merged'][0]:.2f} frames/s over {res['merged'][1]} frames",
-               "merged_1thread_frames_per_s": res["merged"][0]}
+               "sample": f"oracle FastTsdfIntegrator restatement (the integrator the reference's tsdf servers configure), {threads} threads (reference "
+                         f"integrator_threads: 8), first {res['fast'][1]} frames of the same stream, {res['fast'][2]:.1f} s",
+               "same_method": {"method": "merged", "value": res["merged"][0], "unit": "frames/s", "cores": threads,
+                               "sample": f"oracle MergedTsdfIntegrator restatement, {threads} threads, first {res['merged'][1]} frames, {res['merged'][2]:.1f} s"}}
 
     if rank == 0:
         line = {
@@ -332,12 +464,14 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"configs[1]: 1 client per GPU, 640x480 synthetic depth stream, {args.voxel * 100:.0f} cm voxels, "
-                                   f"{args.method} integrator semantics (bit-exact vs CPU oracle), points resident in HBM",
+                                   f"{args.method} integrator semantics (the reference's configured method is fast; bit-exact vs CPU oracle), points resident in HBM",
                        "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
-            "frame_stats_mean": {k: v / max(args.steps, 1) for k, v in stats_sum.items()},
-            "critical_path": dict(stats_max, note="longest sequential chains of any timed frame: points of the largest bundle (k_bundle_merge), "
-                                                  "updates of the busiest voxel (k_apply_*; free-space runs fold)"),
-            "roofline": roofline, "cpu_baseline": cpu, "registration": reg, "distributed_registration": dist_reg, "other_methods": other,
+            "frame_stats_mean": frame_stats,
+            "critical_path": dict(crit, note="longest sequential chains of any timed frame: points of the largest bundle (merged), updates of the busiest voxel") if crit else None,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "gpu_over_cpu": ({"merged": (fps if args.method == "merged" else (other or {}).get("merged", {}).get("value", 0.0)) / cpu["same_method"]["value"],
+                              "fast": (fps if args.method == "fast" else (other or {}).get("fast", {}).get("value", 0.0)) / cpu["value"]} if cpu else None),
+            "other_methods": other, "pcie_inclusive": pcie, "registration": reg, "distributed_registration": dist_reg,
         }
         print(json.dumps(line))
     if world > 1:

@@ -277,6 +277,15 @@ class Integrator:
         self.eng.check(self.eng.fn("integrator_stage_times")(self.h, ms, n, C.c_int(int(reset))), "integrator_stage_times")
         return {"merge": (float(ms[0]), int(n[0])), "apply": (float(ms[1]), int(n[1]))}
 
+    KERNEL_CLASSES = ("merge", "apply", "bundle_hash", "point_sort", "touch_emit", "record_sort", "fast_start", "fast_visits", "fast_sweeps")
+
+    def class_times(self, reset=False):
+        """{class: (ms, regions)} for every kernel class of a frame (cox_kernel_class), HIP events on the kernels' own streams."""
+        k = len(self.KERNEL_CLASSES)
+        ms, n = (C.c_double * k)(), (C.c_uint64 * k)()
+        self.eng.check(self.eng.fn("integrator_class_times")(self.h, ms, n, C.c_int(int(reset))), "integrator_class_times")
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(self.KERNEL_CLASSES)}
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         self.eng.check(self.eng.fn("integrator_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))),

@@ -1357,9 +1357,11 @@ struct cox_integrator {
   // timing of individual kernels (bench roofline); forces eager launches
   bool profiling = false;
   u32 profile_every = 1;  // time the kernels of every n-th frame
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> apply_events, merge_events;
-  double apply_ms = 0.0, merge_ms = 0.0;
-  uint64_t apply_launches = 0, merge_launches = 0;
+  // one (begin, end) event pair per timed region of a frame, by kernel class (cox_kernel_class in coxgraph_hip.h)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[COX_KERNEL_CLASSES];
+  std::vector<hipEvent_t> event_pool;
+  double class_ms[COX_KERNEL_CLASSES] = {};
+  uint64_t class_regions[COX_KERNEL_CLASSES] = {};
 };
 
 template <typename T>
@@ -1535,6 +1537,39 @@ static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n,
 
 static inline dim3 grid_for(u32 n, u32 block = 256, u32 cap = 0x7FFFFFFFu) { return dim3(std::min<u32>(cap, std::max<u32>(1, (n + block - 1) / block))); }
 
+// HIP-event timing of one kernel class inside a frame (bench.py roofline): begin / end on the stream the kernels run on
+struct TimedRegion {
+  cox_integrator* I;
+  int cls;
+  hipStream_t s;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  TimedRegion(cox_integrator* I_, int cls_, hipStream_t s_) : I(I_), cls(cls_), s(s_) {
+    if (!(I->profiling && (I->frame_no % I->profile_every == 0))) return;
+    // events come from a pool that the drain refills: creating them costs more than recording them
+    auto take = [&]() -> hipEvent_t {
+      if (!I->event_pool.empty()) {
+        hipEvent_t e = I->event_pool.back();
+        I->event_pool.pop_back();
+        return e;
+      }
+      hipEvent_t e = nullptr;
+      return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    };
+    e0 = take();
+    e1 = take();
+    if (!e0 || !e1) {
+      e0 = e1 = nullptr;
+      return;
+    }
+    (void)hipEventRecord(e0, s);
+  }
+  ~TimedRegion() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, s);
+    I->class_events[cls].emplace_back(e0, e1);
+  }
+};
+
 // ---- the four stages; identical whether launched eagerly or captured into a graph: no argument depends on the frame ----
 struct StageCtx {
   cox_integrator* I;
@@ -1557,10 +1592,14 @@ static int stage_a1(const StageCtx& c, hipStream_t s) {
   COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
   if (I->method == COX_METHOD_MERGED) {
     const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
-    COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
-    hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
-                       B.pslot, F.cnt);
-    hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
+    {
+      TimedRegion t(I, COX_KC_BUNDLE_HASH, s);
+      COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
+      hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
+                         B.pslot, F.cnt);
+      hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
+    }
+    TimedRegion t(I, COX_KC_POINT_SORT, s);
     (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I), I->sort_pts,
                                B.sort_info, s);
   }
@@ -1577,18 +1616,8 @@ static int stage_a2(const StageCtx& c, hipStream_t s) {
     // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
     exclusive_scan_u32(B.head, B.head, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
     hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
-    hipEvent_t m0 = nullptr, m1 = nullptr;
-    const bool timed = I->profiling && (I->frame_no % I->profile_every == 0);
-    if (timed) {
-      COX_HIP(hipEventCreate(&m0));
-      COX_HIP(hipEventCreate(&m1));
-      COX_HIP(hipEventRecord(m0, s));
-    }
+    TimedRegion t(I, COX_KC_MERGE, s);
     hipLaunchKernelGGL(k_bundle_merge, dim3(4096), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt);
-    if (timed) {
-      COX_HIP(hipEventRecord(m1, s));
-      I->merge_events.emplace_back(m0, m1);
-    }
   } else {
     hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, F.d_params, F.rays, F.cnt);
   }
@@ -1627,6 +1656,7 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   const u32 fh_mask = I->fh_cap - 1;
   const bool merged = I->method == COX_METHOD_MERGED;
+  TimedRegion* t_walk = new TimedRegion(I, COX_KC_TOUCH_EMIT, s);
   if (merged)  // a few thousand bundles: one launch
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, &F.cnt->n_records);
   else
@@ -1646,6 +1676,8 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
                        F.fh_keys, fh_mask, S.touched_slots, S.ord_info);
   }
+  delete t_walk;
+  TimedRegion t_sort(I, COX_KC_RECORD_SORT, s);
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
   // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
   // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
@@ -1659,20 +1691,10 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   RecordSet& S = *c.S;
   const LayerView L = layer_view(I->layer);
   RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &F.cnt->n_records};
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = I->profiling && (I->frame_no % I->profile_every == 0);
-  if (timed) {
-    COX_HIP(hipEventCreate(&e0));
-    COX_HIP(hipEventCreate(&e1));
-    COX_HIP(hipEventRecord(e0, s));
-  }
+  TimedRegion t(I, COX_KC_APPLY, s);
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
   hipLaunchKernelGGL(k_apply_long, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
                      I->layer->d_err, I->layer->h_nblocks);
-  if (timed) {
-    COX_HIP(hipEventRecord(e1, s));
-    I->apply_events.emplace_back(e0, e1);
-  }
   return COX_OK;
 }
 typedef int (*StageFn)(const StageCtx&, hipStream_t);
@@ -1736,12 +1758,15 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
   COX_HIP(hipMemsetAsync(X.d_changed, 0, sizeof(u32) * kFastMaxSweeps, s));
   // start set: sort the points by slot (21 key bits: slot + "not integrated"), compare neighbours
+  TimedRegion* t_fast = new TimedRegion(I, COX_KC_FAST_START, s);
   hipLaunchKernelGGL(k_fast_points, gp, dim3(256), 0, s, F.d_params, FF, X.fhash, B.skey[0], B.sval[0], F.cnt);
   const int pp = radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, kFastSlotBits + 1, false, 2, I->sort_pts, nullptr, s);
   hipLaunchKernelGGL(k_fast_start_flags, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start, X.fresh);
   hipLaunchKernelGGL(k_fast_start_commit, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start);
   exclusive_scan_u32(X.fresh, X.rank, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
   hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, X.cap, X.cap0, F.cnt);
+  delete t_fast;
+  t_fast = nullptr;
   // Jacobi sweeps until one changes nothing.  (Capturing a batch into a HIP graph was measured: no gain, the sweeps are
   // bound by their own dependent loads, not by launches.)
   // sweeps between two looks at the "changed" flags.  Most frames settle within a handful of sweeps, the first frames of a
@@ -1752,6 +1777,7 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   FastVisits V{};
   for (int round = 0;; ++round) {
     // candidate visits: the first cap[r] voxels of every ray's walk, sorted by slot of the observed set
+    t_fast = new TimedRegion(I, COX_KC_FAST_VISITS, s);
     exclusive_scan_u32(X.cap, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
     if (I->small_axis_cap)
       hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
@@ -1763,6 +1789,8 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
                                         kFastSlotBits, false, 2, I->sort_rec, nullptr, s);
     hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
     V = FastVisits{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
+    delete t_fast;
+    t_fast = new TimedRegion(I, COX_KC_FAST_SWEEPS, s);
     auto enqueue = [&](int first, int count) -> int {
       for (int k = first; k < first + count; ++k) {
         hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
@@ -1789,6 +1817,8 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
       COX_HIP(hipEventSynchronize(X.ev[k & 1]));
       if (X.h_changed[checked_last] == 0) break;
     }
+    delete t_fast;
+    t_fast = nullptr;
     if (X.cap0 == 0xFFFFFFFFu) break;  // whole walks from the start: nothing to grow
     // did a ray reach the end of its candidate list without stopping?  (flag in the next free slot of the sweep flags)
     hipLaunchKernelGGL(k_fast_grow_caps, gr, dim3(256), 0, s, F.rays.nsteps, X.cap, X.reach[sweep & 1], X.reach[(sweep + 1) & 1], X.d_changed + sweep, F.cnt);
@@ -1935,15 +1965,15 @@ static int fold_counters(cox_integrator* I) {
   return COX_OK;
 }
 
-static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc) {
+static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc, std::vector<hipEvent_t>* pool) {
   for (auto& ev : evs) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
       *ms_acc += ms;
       *n_acc += 1;
     }
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+    pool->push_back(ev.first);
+    pool->push_back(ev.second);
   }
   evs.clear();
 }
@@ -1959,8 +1989,7 @@ static int integrator_finish(cox_integrator* I) {
     COX_HIP(hipMemset(I->layer->d_err, 0, sizeof(u32)));
     COX_HIP(hipDeviceSynchronize());  // default-stream memset: the engine's streams would not wait for it
   }
-  drain_events(I->apply_events, &I->apply_ms, &I->apply_launches);
-  drain_events(I->merge_events, &I->merge_ms, &I->merge_launches);
+  for (int k = 0; k < COX_KERNEL_CLASSES; ++k) drain_events(I->class_events[k], &I->class_ms[k], &I->class_regions[k], &I->event_pool);
   return err_bits_to_status(lerr);
 }
 
@@ -2070,11 +2099,12 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   (void)hipSetDevice(I->layer->device);
   (void)sync_all(I);
   drop_graphs(I);
-  for (auto* evs : {&I->apply_events, &I->merge_events})
-    for (auto& e : *evs) {
+  for (auto& evs : I->class_events)
+    for (auto& e : evs) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
+  for (hipEvent_t e : I->event_pool) (void)hipEventDestroy(e);
   std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums};
   {
@@ -2201,11 +2231,11 @@ int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* 
   if (!I) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   int st = integrator_finish(I);
-  if (apply_ms) *apply_ms = I->apply_ms;
-  if (apply_launches) *apply_launches = I->apply_launches;
+  if (apply_ms) *apply_ms = I->class_ms[COX_KC_APPLY];
+  if (apply_launches) *apply_launches = I->class_regions[COX_KC_APPLY];
   if (reset) {
-    I->apply_ms = 0.0;
-    I->apply_launches = 0;
+    I->class_ms[COX_KC_APPLY] = 0.0;
+    I->class_regions[COX_KC_APPLY] = 0;
   }
   return st;
 }
@@ -2232,13 +2262,30 @@ int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launc
   if (!I || !ms || !launches) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   int st = integrator_finish(I);
-  ms[0] = I->merge_ms;
-  launches[0] = I->merge_launches;
-  ms[1] = I->apply_ms;
-  launches[1] = I->apply_launches;
-  if (reset) {
-    I->merge_ms = I->apply_ms = 0.0;
-    I->merge_launches = I->apply_launches = 0;
+  ms[0] = I->class_ms[COX_KC_MERGE];
+  launches[0] = I->class_regions[COX_KC_MERGE];
+  ms[1] = I->class_ms[COX_KC_APPLY];
+  launches[1] = I->class_regions[COX_KC_APPLY];
+  if (reset)
+    for (int k : {COX_KC_MERGE, COX_KC_APPLY}) {
+      I->class_ms[k] = 0.0;
+      I->class_regions[k] = 0;
+    }
+  return st;
+}
+
+int cox_integrator_class_times(cox_integrator_t* I, double ms[COX_KERNEL_CLASSES], uint64_t regions[COX_KERNEL_CLASSES], int reset) {
+  COX_ENTRY();
+  if (!I || !ms || !regions) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  int st = integrator_finish(I);
+  for (int k = 0; k < COX_KERNEL_CLASSES; ++k) {
+    ms[k] = I->class_ms[k];
+    regions[k] = I->class_regions[k];
+    if (reset) {
+      I->class_ms[k] = 0.0;
+      I->class_regions[k] = 0;
+    }
   }
   return st;
 }

@@ -185,6 +185,23 @@ int cox_integrator_kernel_time(cox_integrator_t* integ, double* apply_ms, uint64
  * frame), [1] = the TSDF update stage (k_apply_eval + k_apply_long) */
 int cox_integrator_stage_times(cox_integrator_t* integ, double ms[2], uint64_t launches[2], int reset);
 
+/* the same for every kernel class of a frame: ms[k] = accumulated HIP-event time of the regions of class k since the last
+ * reset, regions[k] = how many regions that is (one region = the consecutive launches of that class in one frame; the
+ * sweeps of the fast integrator are one region per round) */
+typedef enum cox_kernel_class {
+  COX_KC_MERGE = 0,       /* k_bundle_merge (merged: the bundles' sequential means) */
+  COX_KC_APPLY = 1,       /* k_apply_eval + k_apply_long (the TSDF update) */
+  COX_KC_BUNDLE_HASH = 2, /* frame hash memset + k_bundle_insert + k_bundle_keys (merged) */
+  COX_KC_POINT_SORT = 3,  /* radix sort of the points (merged: bundling) */
+  COX_KC_TOUCH_EMIT = 4,  /* record offsets + touch (block allocation) + emit */
+  COX_KC_RECORD_SORT = 5, /* radix sort of the (voxel, ray) records */
+  COX_KC_FAST_START = 6,  /* fast: start-set sort + flags + ray list */
+  COX_KC_FAST_VISITS = 7, /* fast: candidate visits + their sort + inverse */
+  COX_KC_FAST_SWEEPS = 8, /* fast: the Jacobi sweeps of one round */
+  COX_KERNEL_CLASSES = 9
+} cox_kernel_class;
+int cox_integrator_class_times(cox_integrator_t* integ, double ms[COX_KERNEL_CLASSES], uint64_t regions[COX_KERNEL_CLASSES], int reset);
+
 /* self-test: the merged integrator evaluates its sequential mean with an IEEE division whose divisor-only part is
  * hoisted out of the dependent chain; this compares it bit for bit with the compiler's '/' on n pseudo-random operand
  * pairs in the range the kernel accepts and returns the number of differing results (must be 0) */
