@@ -15,7 +15,7 @@ STATUS = {
     -4: "COX_ERR_POOL_EXHAUSTED", -5: "COX_ERR_INDEX_RANGE", -6: "COX_ERR_UNSUPPORTED",
     -7: "COX_ERR_BUFFER_TOO_SMALL", -8: "COX_ERR_INTERNAL",
 }
-METHODS = {"simple": 0, "merged": 1, "fast": 2}
+METHODS = {"simple": 0, "merged": 1, "fast": 2, "projective": 3}
 VOXELS_PER_BLOCK = 4096
 
 
@@ -37,6 +37,9 @@ class TsdfConfig(C.Structure):
         ("start_voxel_subsampling_factor", C.c_float), ("max_consecutive_ray_collisions", C.c_int32),
         ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float),
         ("merged_bundle_order", C.c_int32), ("fast_exact_sets", C.c_int32),
+        ("sensor_horizontal_resolution", C.c_int32), ("sensor_vertical_resolution", C.c_int32),
+        ("sensor_vertical_field_of_view_degrees", C.c_float), ("projective_interpolation_scheme", C.c_int32),
+        ("projective_adaptive_gap_m", C.c_float),
     ]
 
 
@@ -243,6 +246,12 @@ class Integrator:
             assert rgba.shape == (n, 4)
         self.eng.check(self.eng.fn("integrate_points")(self.h, _fp(T), _fp(xyz), _fp(rgba) if rgba is not None else None,
                                                        C.c_uint64(n), C.c_int(int(freespace))), "integrate_points")
+
+    def deintegrate_points(self, T_G_C, xyz):
+        """integratePointCloud(..., deintegrate = true): projective integrator only."""
+        T = np.ascontiguousarray(T_G_C, np.float32)
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        self.eng.check(self.eng.fn("integrate_points_ex")(self.h, _fp(T), _fp(xyz), None, C.c_uint64(xyz.shape[0]), C.c_int(0), C.c_int(1)), "integrate_points_ex")
 
     def integrate_points_dev(self, T_G_C, xyz_ptr, rgba_ptr, n, freespace=False):
         T = np.ascontiguousarray(T_G_C, np.float32)

@@ -1319,6 +1319,7 @@ struct FastState {
 };
 
 struct cox_integrator {
+  cox_projective* proj = nullptr;  // method == COX_METHOD_PROJECTIVE: everything else below stays empty
   cox_layer* layer = nullptr;
   FastState fast;
   cox_tsdf_config cfg;
@@ -2000,6 +2001,22 @@ extern "C" {
 int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int method, cox_integrator_t** out) {
   COX_ENTRY();
   if (!layer || !cfg || !out) return COX_ERR_INVALID_ARG;
+  if (method == COX_METHOD_PROJECTIVE) {
+    if (!(cfg->default_truncation_distance > 0.0f) || !(cfg->max_weight > 0.0f) || !(cfg->max_ray_length_m > 0.0f)) return COX_ERR_INVALID_ARG;
+    COX_HIP(hipSetDevice(layer->device));
+    cox_integrator* I = new (std::nothrow) cox_integrator();
+    if (!I) return COX_ERR_OUT_OF_MEMORY;
+    I->layer = layer;
+    I->cfg = *cfg;
+    I->method = method;
+    const int st = cox_proj_create(layer, cfg, &I->proj);
+    if (st != COX_OK) {
+      delete I;
+      return st;
+    }
+    *out = I;
+    return COX_OK;
+  }
   if (method != COX_METHOD_SIMPLE && method != COX_METHOD_MERGED && method != COX_METHOD_FAST) return COX_ERR_INVALID_ARG;
   if (cfg->integration_order_mode != 0) return COX_ERR_UNSUPPORTED;
   if (method == COX_METHOD_FAST) {
@@ -2096,6 +2113,11 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
 
 void cox_integrator_destroy(cox_integrator_t* I) {
   if (!I) return;
+  if (I->proj) {
+    cox_proj_destroy(I->proj);
+    delete I;
+    return;
+  }
   (void)hipSetDevice(I->layer->device);
   (void)sync_all(I);
   drop_graphs(I);
@@ -2156,13 +2178,25 @@ int cox_integrate_points_dev(cox_integrator_t* I, const float T_G_C[7], const fl
   COX_ENTRY();
   if (!I || !T_G_C || (n && !xyz_dev) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
+  if (I->proj) return cox_proj_integrate(I->proj, T_G_C, xyz_dev, n, 0);
   return integrate_device(I, T_G_C, xyz_dev, rgba_dev, static_cast<u32>(n), freespace);
+}
+
+int cox_integrate_points_ex(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace, int deintegrate) {
+  if (!I) return COX_ERR_INVALID_ARG;
+  if (!deintegrate) return cox_integrate_points(I, T_G_C, xyz, rgba, n, freespace);
+  COX_ENTRY();
+  if (!I->proj) return COX_ERR_UNSUPPORTED;  // only the projective integrator can take a cloud out again
+  if (!T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 1);
 }
 
 int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
   COX_ENTRY();
   if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
+  if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
   COX_TRY(sync_all(I));  // the staging buffers may still feed an earlier frame
   if (n) {
@@ -2176,6 +2210,7 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
 int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4]) {
   COX_ENTRY();
   if (!I || !T_G_C || !depth_dev || !K || w <= 0 || h <= 0 || static_cast<uint64_t>(w) * h > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  if (I->proj) return COX_ERR_UNSUPPORTED;  // the projective integrator takes point clouds (it builds its own range image)
   COX_HIP(hipSetDevice(I->layer->device));
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
@@ -2205,6 +2240,7 @@ int cox_integrator_sync(cox_integrator_t* I) {
   COX_ENTRY();
   if (!I) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
+  if (I->proj) return cox_proj_sync(I->proj);
   return integrator_finish(I);
 }
 
@@ -2212,6 +2248,7 @@ int cox_integrator_last_stats(cox_integrator_t* I, cox_frame_stats* stats) {
   COX_ENTRY();
   if (!I || !stats) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
+  if (I->proj) return cox_proj_last_stats(I->proj, stats);
   COX_TRY(sync_all(I));
   COX_TRY(fold_counters(I));
   *stats = I->last;
@@ -2229,6 +2266,7 @@ int cox_integrator_set_profiling(cox_integrator_t* I, int on) {
 int cox_integrator_kernel_time(cox_integrator_t* I, double* apply_ms, uint64_t* apply_launches, int reset) {
   COX_ENTRY();
   if (!I) return COX_ERR_INVALID_ARG;
+  if (I->proj) return COX_ERR_UNSUPPORTED;
   COX_HIP(hipSetDevice(I->layer->device));
   int st = integrator_finish(I);
   if (apply_ms) *apply_ms = I->class_ms[COX_KC_APPLY];
@@ -2260,6 +2298,7 @@ int cox_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t* misma
 int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launches[2], int reset) {
   COX_ENTRY();
   if (!I || !ms || !launches) return COX_ERR_INVALID_ARG;
+  if (I->proj) return COX_ERR_UNSUPPORTED;
   COX_HIP(hipSetDevice(I->layer->device));
   int st = integrator_finish(I);
   ms[0] = I->class_ms[COX_KC_MERGE];
@@ -2277,6 +2316,7 @@ int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launc
 int cox_integrator_class_times(cox_integrator_t* I, double ms[COX_KERNEL_CLASSES], uint64_t regions[COX_KERNEL_CLASSES], int reset) {
   COX_ENTRY();
   if (!I || !ms || !regions) return COX_ERR_INVALID_ARG;
+  if (I->proj) return COX_ERR_UNSUPPORTED;
   COX_HIP(hipSetDevice(I->layer->device));
   int st = integrator_finish(I);
   for (int k = 0; k < COX_KERNEL_CLASSES; ++k) {

@@ -94,3 +94,12 @@ static inline void cox_clear_stale_hip_error(const char* where) {
 
 // the layer an integrator writes to (cox_integrator is private to cox_integrator.hip)
 cox_layer* cox_internal_integrator_layer(cox_integrator_t* integ);
+
+// voxblox ProjectiveTsdfIntegrator (cox_projective.hip), reached through the integrator handle when method == COX_METHOD_PROJECTIVE
+struct cox_projective;
+int cox_proj_create(cox_layer* layer, const cox_tsdf_config* cfg, cox_projective** out);
+void cox_proj_destroy(cox_projective* P);
+int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev, uint64_t n, int deintegrate);
+int cox_proj_integrate_host(cox_projective* P, const float T[7], const float* xyz, uint64_t n, int deintegrate);
+int cox_proj_sync(cox_projective* P);
+int cox_proj_last_stats(cox_projective* P, cox_frame_stats* out);

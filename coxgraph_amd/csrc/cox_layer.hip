@@ -105,6 +105,11 @@ void cox_tsdf_config_default(cox_tsdf_config* c) {
   c->max_integration_time_s = 3.4e38f;
   c->merged_bundle_order = 0;
   c->fast_exact_sets = 0;
+  c->sensor_horizontal_resolution = 0;
+  c->sensor_vertical_resolution = 0;
+  c->sensor_vertical_field_of_view_degrees = 0.0f;
+  c->projective_interpolation_scheme = 3;
+  c->projective_adaptive_gap_m = 0.5f;
 }
 
 int cox_layer_create(float voxel_size, int voxels_per_side, int device, uint64_t capacity_blocks, cox_layer_t** out) {

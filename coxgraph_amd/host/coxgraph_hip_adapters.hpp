@@ -143,12 +143,13 @@ struct TsdfIntegratorConfig : cox_tsdf_config {
 class TsdfIntegrator {
  public:
   using Ptr = std::shared_ptr<TsdfIntegrator>;
-  // TsdfIntegratorFactory::create(method, config, layer): method in {"simple", "merged", "fast"}
+  // TsdfIntegratorFactory::create(method, config, layer): method in {"simple", "merged", "fast", "projective"}
   static Ptr create(const std::string& method, const TsdfIntegratorConfig& config, TsdfLayer* layer) {
     int m = -1;
     if (method == "simple") m = COX_METHOD_SIMPLE;
     if (method == "merged") m = COX_METHOD_MERGED;
     if (method == "fast") m = COX_METHOD_FAST;
+    if (method == "projective") m = COX_METHOD_PROJECTIVE;  // config/tsdf_server_default.yaml:6, tsdf_server_carla.yaml:6
     if (m < 0) throw std::runtime_error("Unknown TSDF integrator type: " + method);
     return Ptr(new TsdfIntegrator(m, config, layer));
   }

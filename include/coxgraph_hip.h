@@ -49,10 +49,11 @@ typedef struct cox_integrator cox_integrator_t; /* voxblox::TsdfIntegratorBase *
 typedef struct cox_regpoints cox_regpoints_t;   /* voxgraph registration point set of a submap */
 typedef struct cox_reg cox_reg_t;               /* voxgraph::RegistrationCostFunction */
 
-/* integrator factory key: method in {"simple","merged","fast"}; "fast" reproduces the reference at integrator_threads = 1
+/* integrator factory key: method in {"simple","merged","fast","projective"}; "fast" reproduces the reference at integrator_threads = 1;
+ * "projective" (config/tsdf_server_default.yaml:6-9, tsdf_server_carla.yaml:6-9) is voxblox's range-image gather integrator
  * (coxgraph/config/tsdf_server_euroc.yaml:6, tsdf_server_default.yaml:6,
  *  coxgraph_sim/launch/experiments/mav_3dplanning_2d3dhouse_two.launch:10) */
-typedef enum cox_method { COX_METHOD_SIMPLE = 0, COX_METHOD_MERGED = 1, COX_METHOD_FAST = 2 } cox_method;
+typedef enum cox_method { COX_METHOD_SIMPLE = 0, COX_METHOD_MERGED = 1, COX_METHOD_FAST = 2, COX_METHOD_PROJECTIVE = 3 } cox_method;
 
 /* voxblox::TsdfIntegratorBase::Config as read by getTsdfIntegratorConfigFromRosParam
  * (used by coxgraph/include/coxgraph/map_comm/tsdf_recover.h:48-50; keys in
@@ -78,6 +79,13 @@ typedef struct cox_tsdf_config {
   float max_integration_time_s;           /* fast; a finite budget is refused by the HIP engine (wall-clock dependent) */
   int32_t merged_bundle_order;            /* CPU oracle only: 0 canonical, 1 libstdc++ map order */
   int32_t fast_exact_sets;                /* CPU oracle only: 0 ApproxHashSet, 1 exact sets */
+  /* projective only (sensor_horizontal_resolution / sensor_vertical_resolution / sensor_vertical_field_of_view_degrees,
+   * config/tsdf_server_default.yaml:7-9); the resolutions must be set, voxblox CHECKs them > 0 */
+  int32_t sensor_horizontal_resolution;
+  int32_t sensor_vertical_resolution;
+  float sensor_vertical_field_of_view_degrees;
+  int32_t projective_interpolation_scheme; /* 0 nearest, 1 min neighbour, 2 bilinear, 3 adaptive (what TsdfIntegratorFactory instantiates) */
+  float projective_adaptive_gap_m;         /* adaptive: a 2 x 2 range neighbourhood wider than this is a depth discontinuity */
 } cox_tsdf_config;
 
 /* per-frame counters of the last cox_integrate_* call (used for the roofline accounting of
@@ -152,6 +160,11 @@ void cox_integrator_destroy(cox_integrator_t* integ);
  * -- the call at coxgraph/include/coxgraph/map_comm/tsdf_recover.h:75.
  * xyz: n*3 floats (camera frame), rgba: n*4 bytes or NULL. Host pointers. Synchronous. */
 int cox_integrate_points(cox_integrator_t* integ, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace);
+/* TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace_points, deintegrate): the projective integrator
+ * can take a cloud back out again (voxblox's TsdfServer does so for clouds that leave its queue of
+ * pointcloud_deintegration_queue_length, config/tsdf_server_default.yaml:28).  COX_ERR_UNSUPPORTED for the other methods
+ * with deintegrate != 0. */
+int cox_integrate_points_ex(cox_integrator_t* integ, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace, int deintegrate);
 /* same, inputs already resident on the handle's GPU; asynchronous.
  * ORDERING AND LIFETIME of *_dev inputs.  A frame is enqueued on the engine's own non-blocking streams (ray generation and
  * layer update of consecutive frames overlap), which do not order against any stream of the caller.  Either

@@ -223,6 +223,8 @@ struct RayCaster {
     else
       setup(e, s);
   }
+  // RayCaster(start_scaled, end_scaled): the constructor the projective integrator uses on block-scaled points
+  RayCaster(V3 start_scaled, V3 end_scaled) { setup(start_scaled, end_scaled); }
   void setup(V3 start, V3 end) {
     if (std::isnan(start.x) || std::isnan(start.y) || std::isnan(start.z) || std::isnan(end.x) || std::isnan(end.y) || std::isnan(end.z)) {
       ray_length_in_steps = 0;

@@ -7,6 +7,7 @@
 #include "cox_oracle.hpp"
 #include "cox_oracle_mesh.hpp"
 #include "cox_oracle_submap.hpp"
+#include "cox_oracle_projective.hpp"
 
 #include <map>
 #include <tuple>
@@ -19,6 +20,7 @@ struct coxo_layer {
 };
 struct coxo_integrator {
   std::unique_ptr<Integrator> integ;
+  std::unique_ptr<ProjectiveIntegrator> proj;  // method 3
 };
 struct coxo_regpoints {
   std::vector<RegPoint> pts;
@@ -80,6 +82,12 @@ void coxo_tsdf_config_default(cox_tsdf_config* c) {
   c->max_integration_time_s = d.max_integration_time_s;
   c->merged_bundle_order = 0;
   c->fast_exact_sets = 0;
+  const ProjectiveConfig pc;
+  c->sensor_horizontal_resolution = pc.horizontal_resolution;
+  c->sensor_vertical_resolution = pc.vertical_resolution;
+  c->sensor_vertical_field_of_view_degrees = pc.vertical_fov_deg;
+  c->projective_interpolation_scheme = pc.interpolation_scheme;
+  c->projective_adaptive_gap_m = pc.adaptive_gap_m;
 }
 
 int coxo_layer_create(float voxel_size, int vps, int /*device*/, uint64_t /*capacity*/, coxo_layer** out) {
@@ -148,32 +156,58 @@ int coxo_layer_merge(const coxo_layer* a, const float T[7], coxo_layer* b) {
 }
 
 int coxo_integrator_create(coxo_layer* l, const cox_tsdf_config* cfg, int method, coxo_integrator** out) {
-  if (!l || !cfg || !out || method < 0 || method > 2) return COX_ERR_INVALID_ARG;
+  if (!l || !cfg || !out || method < 0 || method > 3) return COX_ERR_INVALID_ARG;
   auto* h = new coxo_integrator();
+  if (method == 3) {
+    if (cfg->sensor_horizontal_resolution <= 1 || cfg->sensor_vertical_resolution <= 1 || !(cfg->sensor_vertical_field_of_view_degrees > 0.0f)) {
+      delete h;
+      return COX_ERR_INVALID_ARG;
+    }
+    ProjectiveConfig pc;
+    pc.horizontal_resolution = cfg->sensor_horizontal_resolution;
+    pc.vertical_resolution = cfg->sensor_vertical_resolution;
+    pc.vertical_fov_deg = cfg->sensor_vertical_field_of_view_degrees;
+    pc.interpolation_scheme = cfg->projective_interpolation_scheme;
+    pc.adaptive_gap_m = cfg->projective_adaptive_gap_m;
+    h->proj.reset(new ProjectiveIntegrator(&l->layer, toCfg(cfg), pc));
+    *out = h;
+    return COX_OK;
+  }
   h->integ.reset(new Integrator(&l->layer, toCfg(cfg), method));
   *out = h;
   return COX_OK;
 }
 void coxo_integrator_destroy(coxo_integrator* h) { delete h; }
 int coxo_integrator_set_count_touched(coxo_integrator* h, int on) {
-  h->integ->count_touched = on != 0;
+  if (h->integ) h->integ->count_touched = on != 0;
   return COX_OK;
 }
 int coxo_integrate_points(coxo_integrator* h, const float T[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
   Transform Tr{T[0], T[1], T[2], T[3], {T[4], T[5], T[6]}};
   static_assert(sizeof(V3) == 12 && sizeof(Color) == 4, "layout");
+  if (h->proj) {
+    h->proj->integratePointCloud(Tr, reinterpret_cast<const V3*>(xyz), n, false);
+    return COX_OK;
+  }
   h->integ->integratePointCloud(Tr, reinterpret_cast<const V3*>(xyz), reinterpret_cast<const Color*>(rgba), n, freespace != 0);
+  return COX_OK;
+}
+int coxo_integrate_points_ex(coxo_integrator* h, const float T[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace, int deintegrate) {
+  if (!deintegrate) return coxo_integrate_points(h, T, xyz, rgba, n, freespace);
+  if (!h->proj) return COX_ERR_UNSUPPORTED;
+  Transform Tr{T[0], T[1], T[2], T[3], {T[4], T[5], T[6]}};
+  h->proj->integratePointCloud(Tr, reinterpret_cast<const V3*>(xyz), n, true);
   return COX_OK;
 }
 int coxo_integrator_sync(coxo_integrator*) { return COX_OK; }
 int coxo_integrator_last_stats(coxo_integrator* h, cox_frame_stats* s) {
-  const FrameStats& f = h->integ->last_stats;
+  const FrameStats& f = h->proj ? h->proj->last_stats : h->integ->last_stats;
   s->n_points = f.n_points;
   s->n_valid = f.n_valid;
   s->n_rays = f.n_rays;
   s->n_updates = f.n_updates;
   s->n_touched_voxels = f.n_touched_voxels;
-  s->n_touched_blocks = 0;
+  s->n_touched_blocks = h->proj ? h->proj->n_touched_blocks : 0;
   s->n_new_blocks = f.n_new_blocks;
   s->max_bundle_points = f.max_bundle_points;
   s->max_voxel_updates = f.max_voxel_updates;
@@ -499,6 +533,7 @@ int coxo_meshconv_clear(coxo_meshconv* c) {
 }
 int coxo_recover_process_mesh(coxo_meshconv* c, coxo_integrator* integ, const cox_mesh_msg* mesh, uint64_t* n_recovered, uint64_t* n_integrated) {
   if (!c || !integ) return COX_ERR_INVALID_ARG;
+  if (!integ->integ) return COX_ERR_UNSUPPORTED;  // recover mode is configured with a ray-casting integrator (tsdf_recover.yaml:6)
   MeshMsg m;
   const int rc = toMeshMsg(mesh, &m);
   if (rc != COX_OK) return rc;
@@ -615,3 +650,14 @@ int coxo_reg_get_samples(coxo_reg* reg, uint32_t* out, uint64_t cap, uint64_t* n
   return COX_OK;
 }
 }  // extern "C"
+
+// probes for the shared plain-float asin / atan2 (tests/test_oracle_projective.py checks them against float64)
+extern "C" {
+int coxo_math_probe(const float* a, const float* b, uint64_t n, float* asin_out, float* atan2_out) {
+  for (uint64_t i = 0; i < n; ++i) {
+    asin_out[i] = cox_asinf(a[i]);
+    atan2_out[i] = cox_atan2f(a[i], b[i]);
+  }
+  return COX_OK;
+}
+}

@@ -36,7 +36,7 @@ def oracle():
     """The CPU oracle (oracle/libcoxoracle.so, prefix coxo_) -- the checker, never the product."""
     from coxgraph_amd.capi import Engine
     lib = os.path.join(ROOT, "oracle", "libcoxoracle.so")
-    src = [os.path.join(ROOT, "oracle", f) for f in ("cox_oracle.hpp", "cox_oracle_mesh.hpp", "cox_oracle_submap.hpp", "cox_oracle_capi.cpp")]
+    src = [os.path.join(ROOT, "oracle", f) for f in ("cox_oracle.hpp", "cox_oracle_mesh.hpp", "cox_oracle_submap.hpp", "cox_oracle_projective.hpp", "cox_oracle_capi.cpp")]
     if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     return Engine(lib, "coxo_")

@@ -1,0 +1,72 @@
+"""`method: "projective"` (coxgraph/config/tsdf_server_default.yaml:6-9, tsdf_server_carla.yaml:6-9) on the GPU against the
+CPU oracle: block set, per-frame counters and every distance / weight word identical (a voxel is written by one thread per
+frame and the range image keeps a minimum, so there is no order to agree on; the angles come from the shared plain-float
+asin / atan2 of include/coxgraph_hip_math.h)."""
+import numpy as np
+import pytest
+
+from coxgraph_amd import synth
+from coxgraph_amd.capi import Layer, Integrator, CoxError
+from util import compare_layers, compare_stats
+from test_oracle_projective import lidar_cloud, proj_config, IDENT
+
+pytestmark = pytest.mark.gpu
+
+
+def run(eng, cfg_kw, voxel, frames, capacity=8192, deintegrate_first=False):
+    layer = Layer(eng, voxel, capacity_blocks=capacity)
+    integ = Integrator(eng, layer, proj_config(eng, **cfg_kw), "projective")
+    stats = []
+    for T, pts in frames:
+        integ.integrate_points(T, pts, None)
+        stats.append(integ.last_stats())
+    if deintegrate_first:
+        integ.deintegrate_points(*frames[0])
+        stats.append(integ.last_stats())
+    return layer, stats
+
+
+KEYS = ("n_points", "n_valid", "n_rays", "n_updates", "n_touched_voxels", "n_touched_blocks", "n_new_blocks")
+
+
+@pytest.mark.parametrize("scheme", [3, 2, 1, 0])
+def test_lidar_wall_parity(hip, oracle, scheme):
+    frames = [(IDENT, lidar_cloud()), (np.array([0.9990482, 0, 0, 0.0436194, 0.2, -0.1, 0.05], np.float32), lidar_cloud(wall_x=2.8))]
+    kw = dict(projective_interpolation_scheme=scheme)
+    (la, sa), (lb, sb) = run(hip, kw, 0.1, frames), run(oracle, kw, 0.1, frames)
+    compare_stats(sa, sb, keys=KEYS)
+    rep = compare_layers(la, lb, tol=0.0, check_color=False)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["observed"] > 5000, rep
+
+
+@pytest.mark.parametrize("voxel", [0.10, 0.05])
+def test_depth_camera_stream_with_the_reference_sensor_model(hip, oracle, voxel):
+    """The yaml files feed the integrator 1280 x 960 / 360 degrees even for depth cameras: the synthetic 640 x 480 stream
+    through exactly that model, several frames, drop-off and 1/r^2 weights on."""
+    frames = [synth.make_frame(t)[:2] for t in (0, 10, 20, 30)]
+    frames = [(T, p[::2]) for T, p in frames]
+    ov = synth.integrator_overrides(voxel)
+    kw = dict(sensor_horizontal_resolution=1280, sensor_vertical_resolution=960, sensor_vertical_field_of_view_degrees=360.0,
+              default_truncation_distance=ov["default_truncation_distance"], min_ray_length_m=ov["min_ray_length_m"], max_ray_length_m=ov["max_ray_length_m"])
+    for extra in (dict(), dict(use_const_weight=0, use_weight_dropoff=0, voxel_carving_enabled=0)):
+        (la, sa), (lb, sb) = run(hip, dict(kw, **extra), voxel, frames, deintegrate_first=True), run(oracle, dict(kw, **extra), voxel, frames, deintegrate_first=True)
+        compare_stats(sa, sb, keys=KEYS)
+        rep = compare_layers(la, lb, tol=0.0, check_color=False)
+        assert rep["bitexact_d"] and rep["bitexact_w"] and rep["observed"] > 10000, rep
+
+
+def test_projective_layer_grows_and_async_device_path(hip, oracle):
+    import torch
+    frames = [(IDENT, lidar_cloud()), (IDENT, lidar_cloud(wall_x=2.5))]
+    lb, sb = run(oracle, {}, 0.1, frames)
+    layer = Layer(hip, 0.1, capacity_blocks=sb[0]["n_new_blocks"] + 1)   # doubles before the second frame
+    integ = Integrator(hip, layer, proj_config(hip), "projective")
+    dev = [torch.from_numpy(p).cuda() for _, p in frames]
+    torch.cuda.synchronize()
+    for (T, _), x in zip(frames, dev):
+        integ.integrate_points_dev(T, x.data_ptr(), 0, x.shape[0])
+    integ.sync()
+    rep = compare_layers(layer, lb, tol=0.0, check_color=False)
+    assert rep["bitexact_d"] and rep["bitexact_w"]
+    with pytest.raises(CoxError):
+        Integrator(hip, layer, hip.default_config(), "projective")

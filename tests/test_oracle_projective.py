@@ -1,0 +1,97 @@
+"""The projective integrator's CPU restatement (oracle/cox_oracle_projective.hpp): known answers + the shared asin / atan2.
+
+voxblox's ProjectiveTsdfIntegrator is configured by the reference (coxgraph/config/tsdf_server_default.yaml:6-9,
+tsdf_server_carla.yaml:6-9) but its source is not in the tree (recalled with low confidence):
+parity is unpinned; the anchors here are geometric.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from coxgraph_amd.capi import Layer, Integrator, words_to_fields
+
+IDENT = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_shared_asin_atan2_are_within_four_ulp_of_the_exact_values(oracle):
+    rng = np.random.default_rng(0)
+    n = 400000
+    a = np.concatenate([rng.uniform(-1, 1, n), np.array([0.0, 1.0, -1.0, 0.5, -0.5, 1e-5, 0.4999999, 0.5000001])]).astype(np.float32)
+    b = np.concatenate([rng.normal(size=n) * 10.0 ** rng.integers(-3, 4, n), np.array([1.0, 0.0, -0.0, -1.0, 3.0, -2.0, 1e-8, -1e8])]).astype(np.float32)
+    s, t = np.zeros_like(a), np.zeros_like(a)
+    oracle.fn("math_probe")(_fp(a), _fp(b), C.c_uint64(len(a)), _fp(s), _fp(t))
+    ref_s = np.arcsin(a.astype(np.float64))
+    ref_t = np.arctan2(a.astype(np.float64), b.astype(np.float64))
+    ulp = lambda x: np.spacing(np.abs(x).astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(s - ref_s) / ulp(ref_s.astype(np.float32) + np.float32(1e-30))) <= 4.0
+    assert np.max(np.abs(t - ref_t) / ulp(ref_t.astype(np.float32) + np.float32(1e-30))) <= 4.0
+    assert s[n] == 0.0 and abs(s[n + 1] - np.pi / 2) < 1e-7 and abs(s[n + 2] + np.pi / 2) < 1e-7
+
+
+def lidar_cloud(rows=64, cols=1024, fov_deg=60.0, wall_x=3.0):
+    """A spinning lidar at the origin in a corridor: returns on the wall x = wall_x (bearings with a positive x component)."""
+    alt = np.radians(np.linspace(-fov_deg / 2 * 0.9, fov_deg / 2 * 0.9, rows))
+    az = np.linspace(-np.pi, np.pi, cols, endpoint=False) + 1e-3
+    A, Z = np.meshgrid(az, alt)
+    d = np.stack([np.cos(Z) * np.cos(A), np.cos(Z) * np.sin(A), np.sin(Z)], axis=-1).reshape(-1, 3)
+    d = d[d[:, 0] > 0.3]
+    return (d * (wall_x / d[:, 0])[:, None]).astype(np.float32)
+
+
+def proj_config(eng, **kw):
+    base = dict(default_truncation_distance=0.3, use_const_weight=1, min_ray_length_m=0.5, max_ray_length_m=10.0,
+                sensor_horizontal_resolution=1024, sensor_vertical_resolution=64, sensor_vertical_field_of_view_degrees=60.0)
+    base.update(kw)
+    return eng.default_config(**base)
+
+
+def test_wall_known_answer_and_deintegration(oracle):
+    pts = lidar_cloud()
+    layer = Layer(oracle, 0.1)
+    integ = Integrator(oracle, layer, proj_config(oracle), "projective")
+    integ.integrate_points(IDENT, pts, None)
+    st = integ.last_stats()
+    # the last image column is rejected (0 < w < cols - 1) and the steepest bearings return from beyond max_ray_length_m
+    assert len(pts) - 64 <= st["n_valid"] <= len(pts) and 0.9 * len(pts) < st["n_rays"] <= st["n_valid"]
+    assert st["n_updates"] > 5000 and st["n_new_blocks"] == layer.stats()[0] > 10
+    idx, vox = layer.download()
+    d, w, _ = words_to_fields(vox)
+    lin = np.arange(4096)
+    loc = np.stack([lin % 16, (lin // 16) % 16, lin // 256], axis=1)
+    c = ((idx[:, None, :] * 16 + loc[None, :, :]).astype(np.float64) + 0.5) * 0.1
+    r = np.linalg.norm(c, axis=2)
+    # voxels close to the sensor's x axis: range along the bearing = 3 / cos(angle); sdf = range - |voxel|, clamped at the truncation
+    near_axis = (np.abs(c[..., 1]) < 0.3) & (np.abs(c[..., 2]) < 0.3) & (c[..., 0] > 1.0) & (c[..., 0] < 3.25) & (w > 0)
+    assert near_axis.sum() > 100
+    expect = np.minimum(0.3, 3.0 * r / c[..., 0] - r)
+    assert np.max(np.abs(d[near_axis] - expect[near_axis])) < 0.02     # range-image pixel size at 3 m is ~2 cm
+    assert np.all(w[near_axis] <= 1.0 + 1e-6) and np.all(d[w > 0] >= -0.3 - 1e-6) and np.all(d[w > 0] <= 0.3 + 1e-6)
+    behind = (c[..., 0] > 3.4) & (np.abs(c[..., 1]) < 0.3) & (np.abs(c[..., 2]) < 0.3)
+    assert np.all(w[behind] == 0)                                        # sdf < -truncation: skipped
+    # a second observation doubles the weights, leaves the distances; taking both clouds out again empties the map
+    integ.integrate_points(IDENT, pts, None)
+    d2, w2, _ = words_to_fields(layer.download()[1])
+    assert np.allclose(w2[near_axis], 2 * w[near_axis]) and np.allclose(d2[near_axis], d[near_axis], atol=1e-6)
+    integ.deintegrate_points(IDENT, pts)
+    integ.deintegrate_points(IDENT, pts)
+    d3, w3, _ = words_to_fields(layer.download()[1])
+    # (behind the surface the drop-off clamps a negative observation weight to 0 -- `max(weight, 0)` after the sign was set, as
+    # restated from upstream -- so those voxels keep their weight; everything in front of the surface goes back to unobserved)
+    front = near_axis & (expect > -0.1 + 1e-3)
+    assert front.sum() > 100 and np.all(w3[front] == 0) and np.all(d3[front] == 0)
+
+
+def test_projective_needs_its_sensor_model(oracle):
+    from coxgraph_amd.capi import CoxError
+    layer = Layer(oracle, 0.1)
+    with pytest.raises(CoxError):
+        Integrator(oracle, layer, oracle.default_config(), "projective")   # resolutions unset: voxblox CHECKs them > 0
+    integ = Integrator(oracle, layer, oracle.default_config(), "merged")
+    with pytest.raises(CoxError) as e:
+        integ.deintegrate_points(IDENT, np.zeros((1, 3), np.float32))
+    assert e.value.status == -6
