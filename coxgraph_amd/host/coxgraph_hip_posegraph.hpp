@@ -137,6 +137,11 @@ class PoseGraph {
   std::vector<RegistrationConstraint> reg;        // forced registration constraints (addForceRegistrationConstraint): kept
   std::vector<RegistrationConstraint> overlap_reg;  // overlap-driven ones: rebuilt by updateRegistrationConstraints()
   uint64_t solve_counter = 0;                     // seeds the weighted sampler: fresh, reproducible draws per solve
+  // multi-GPU server: registration constraint k is evaluated by rank k % world only; every evaluation sums ONE packed
+  // buffer ((4F)^2 + 4F + 1 doubles) over the ranks with RCCL (cox_comm_allreduce_f64), then all ranks solve the same
+  // small system redundantly -- no broadcast needed.  Every rank holds the whole graph (constraints it does not own need
+  // no evaluator: cost == nullptr).
+  cox_comm_t* comm = nullptr;
 
   void resetRegistrationConstraints() { overlap_reg.clear(); }
   void resetSubmapRelativePoseConstraints() { submap_rel.clear(); }
@@ -191,9 +196,23 @@ class PoseGraph {
     };
     if (!exclude_registration) {
       // begin every constraint's evaluation, then collect: the kernels overlap, one latency round per evaluation of the graph
+      int rank = 0, world = 1;
+      if (comm) check(cox_comm_rank(comm, &rank, &world), "comm rank");
       std::vector<const RegistrationConstraint*> all;
-      for (const RegistrationConstraint& c : reg) all.push_back(&c);
-      for (const RegistrationConstraint& c : overlap_reg) all.push_back(&c);
+      size_t k_all = 0;
+      for (const auto* list : {&reg, &overlap_reg})
+        for (const RegistrationConstraint& c : *list)
+          if (static_cast<int>(k_all++ % static_cast<size_t>(world)) == rank) all.push_back(&c);
+      std::vector<double> g_keep, H_keep;
+      double cost_keep = 0.0;
+      if (comm) {  // accumulate this rank's share on its own, reduce it, then add the (redundantly evaluated) rest
+        g_keep.assign(n, 0.0);
+        H_keep.assign(static_cast<size_t>(n) * n, 0.0);
+        g_keep.swap(*g);
+        H_keep.swap(*H);
+        cost_keep = cost;
+        cost = 0.0;
+      }
       for (const RegistrationConstraint* cp : all)
         if (!cp->cost->BeginNormalEquations(P.at(cp->a).v, P.at(cp->b).v)) throw std::runtime_error("registration constraint: begin failed");
       for (const RegistrationConstraint* cp : all) {
@@ -209,6 +228,16 @@ class PoseGraph {
           }
         scatter(c.a, c.b, Haa, Hab, Hbb, b8, b8 + 4);
         cost += ck;
+      }
+      if (comm) {
+        std::vector<double> buf(static_cast<size_t>(n) * n + n + 1);
+        std::copy(H->begin(), H->end(), buf.begin());
+        std::copy(g->begin(), g->end(), buf.begin() + static_cast<size_t>(n) * n);
+        buf.back() = cost;
+        check(cox_comm_allreduce_f64(comm, buf.data(), buf.size()), "all-reduce of the normal equations");
+        for (size_t i = 0; i < H->size(); ++i) (*H)[i] = H_keep[i] + buf[i];
+        for (int i = 0; i < n; ++i) (*g)[i] = g_keep[i] + buf[static_cast<size_t>(n) * n + i];
+        cost = cost_keep + buf.back();
       }
     }
     for (const auto* list : {&rel, &submap_rel})
@@ -248,7 +277,7 @@ class PoseGraph {
       for (auto* list : {&reg, &overlap_reg})
         for (RegistrationConstraint& c : *list) {
           ++k;
-          if (c.sampling_ratio >= 0.0) c.cost->drawSamples(static_cast<uint64_t>(c.sampling_ratio * static_cast<double>(c.cost->num_points())), solve_counter * 1000003ull + k);
+          if (c.cost && c.sampling_ratio >= 0.0) c.cost->drawSamples(static_cast<uint64_t>(c.sampling_ratio * static_cast<double>(c.cost->num_points())), solve_counter * 1000003ull + k);
         }
     }
     std::vector<double> g, H, g2, H2;

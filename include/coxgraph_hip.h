@@ -305,6 +305,27 @@ int cox_reg_get_samples(cox_reg_t* reg, uint32_t* sample_idx, uint64_t cap, uint
 /* HIP-event time of the registration kernel since last reset (bench.py) */
 int cox_reg_kernel_time(cox_reg_t* reg, double* ms, uint64_t* launches, int reset);
 
+/* ---- multi-GPU: RCCL behind the C ABI ---------------------------------------------------------------
+ * One rank = one process = one GPU (a coxgraph client, or the server's share of the constraints).  The reference's star
+ * topology -- the server pulls whole submaps over TCPROS one by one (src/server/client_handler.cpp:82-104,
+ * src/server/coxgraph_server.cpp:119-128,253-258), Ceres sums all residual blocks in one process
+ * (include/coxgraph/server/backend/pose_graph.h:52-73) -- becomes two collectives over xGMI:
+ *   cox_comm_allgather_dev   the submap exchange: every rank's device-resident wire arrays (cox_layer_export_dev,
+ *                            cox_regpoints_data_dev) to every rank; receivers rebuild with cox_layer_upload_dev / cox_regpoints_create_dev
+ *   cox_comm_allreduce_f64   the packed (4N)^2 + 4N + 1 doubles of one pose-graph evaluation, summed with ONE all-reduce
+ * rank 0 makes the id (cox_comm_unique_id) and hands it to the others by whatever channel the application has (the
+ * reference would use a ROS topic); librccl.so is loaded on first use, COX_ERR_UNSUPPORTED without it. */
+#define COX_COMM_ID_BYTES 128
+typedef struct cox_comm cox_comm_t;
+int cox_comm_unique_id(uint8_t id[COX_COMM_ID_BYTES]);
+int cox_comm_init_rank(int device, int rank, int world, const uint8_t id[COX_COMM_ID_BYTES], cox_comm_t** out);
+void cox_comm_destroy(cox_comm_t* comm);
+int cox_comm_rank(const cox_comm_t* comm, int* rank, int* world);
+/* host buffer in, host buffer out (the payload is KBs and the solver reads it on the host) */
+int cox_comm_allreduce_f64(cox_comm_t* comm, double* buf, uint64_t n);
+/* recv_dev holds world * bytes_per_rank bytes, rank r's part at offset r * bytes_per_rank; device pointers */
+int cox_comm_allgather_dev(cox_comm_t* comm, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+
 /* ---- recover mode: mesh-with-history -> per-pose point clouds -> integrator ------------------ */
 /* voxblox::MeshConverter (coxgraph/include/coxgraph/map_comm/mesh_converter.h:22-289), the front end of the only
  * in-tree integrator call (TsdfRecover::processMesh, map_comm/tsdf_recover.h:59-99).  A voxblox_msgs/Mesh with

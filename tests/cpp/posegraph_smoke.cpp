@@ -146,6 +146,34 @@ static int serverFlow() {
   const size_t n_before = collection->getSubmapPtr(0)->getRegistrationPoints(RegistrationPointType::kVoxels)->size();
   collection->mergeToCliMap(again);
   if (collection->getSubmapPtr(0)->getRegistrationPoints(RegistrationPointType::kVoxels)->size() < n_before) return 26;
+  // RCCL from the C++ host: a communicator of one rank (what this box can hold) sums the packed normal equations through
+  // ncclAllReduce and must leave the solve unchanged; its all-gather hands a device buffer back unchanged
+  {
+    uint8_t id[COX_COMM_ID_BYTES];
+    const int st = cox_comm_unique_id(id);
+    if (st == COX_ERR_UNSUPPORTED) {
+      std::printf("librccl.so not found: communicator path skipped\n");
+    } else {
+      if (st != COX_OK) return 30;
+      cox_comm_t* comm = nullptr;
+      if (cox_comm_init_rank(0, 0, 1, id, &comm) != COX_OK) return 31;
+      PoseGraphInterface with(pg), without(pg);
+      for (PoseGraphInterface* g : {&with, &without}) {
+        g->poseGraph().poses[2] = Pose4();
+        for (int k = 0; k < 4; ++k) g->poseGraph().poses[2].v[k] = believed[2][k];
+        g->poseGraph().solve_counter = 77;
+      }
+      with.poseGraph().comm = comm;
+      with.optimize(true);
+      without.optimize(true);
+      for (int k = 0; k < 4; ++k)
+        if (with.getPoseMap().at(2).v[k] != without.getPoseMap().at(2).v[k]) return 32;
+      double probe[5] = {1.5, -2.0, 3.25, 0.0, 1e-300};
+      if (cox_comm_allreduce_f64(comm, probe, 5) != COX_OK || probe[0] != 1.5 || probe[2] != 3.25 || probe[4] != 1e-300) return 33;
+      cox_comm_destroy(comm);
+      std::printf("rccl communicator (1 rank): all-reduce of the normal equations leaves the solve bit-identical\n");
+    }
+  }
   std::printf("server flow ok\n");
   return 0;
 }
