@@ -234,6 +234,17 @@ __global__ void __launch_bounds__(256) k_bundle_keys(const FrameParams* __restri
   skey[seq] = k;
   sval[seq] = seq;
 }
+// The frame hash is sized for "every point its own bundle" (6 MB) but a frame fills a few thousand slots: instead of a memset
+// per frame, the slots the frame used are put back to empty once its keys have been read (duplicates write the same words).
+__global__ void __launch_bounds__(256) k_bundle_clear(const FrameParams* __restrict__ Pp, const u32* __restrict__ pslot, u64* __restrict__ fh_keys,
+                                                      u32* __restrict__ fh_first) {
+  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Pp->n_points) return;
+  const u32 slot = pslot[idx];
+  if (slot == kInvalid) return;
+  fh_keys[slot] = kEmptyKey;
+  fh_first[slot] = 0xFFFFFFFFu;
+}
 // the two ping-pong buffers of the bundling sort + where its result ended up
 struct BundleView {
   const u32* key[2];
@@ -1434,6 +1445,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&R.rec_off, cap));
     COX_TRY(dev_realloc(&F.fh_keys, static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
     F.fh_first = reinterpret_cast<u32*>(F.fh_keys + I->fh_cap);
+    COX_HIP(hipMemset(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap));  // empty; every frame leaves it empty again
   }
   for (BundleSet& B : I->bs) {
     COX_TRY(dev_realloc(&B.pslot, cap));
@@ -1595,10 +1607,14 @@ static int stage_a1(const StageCtx& c, hipStream_t s) {
     const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
     {
       TimedRegion t(I, COX_KC_BUNDLE_HASH, s);
-      COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
+      // with anti-grazing the hash is read again by touch / emit (stage B1), after this frame's pslot may have been reused:
+      // that (rare) configuration keeps the memset; otherwise the frame cleans up after itself (k_bundle_clear)
+      const bool self_clean = !I->cfg.enable_anti_grazing;
+      if (!self_clean) COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
       hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
                          B.pslot, F.cnt);
       hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
+      if (self_clean) hipLaunchKernelGGL(k_bundle_clear, grid_for(n), dim3(256), 0, s, F.d_params, B.pslot, F.fh_keys, F.fh_first);
     }
     TimedRegion t(I, COX_KC_POINT_SORT, s);
     (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I), I->sort_pts,

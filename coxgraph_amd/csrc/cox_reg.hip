@@ -115,30 +115,46 @@ __device__ __forceinline__ PointResult reg_point(const ReadingView& L, const Rel
     const float c0 = static_cast<float>(b[k]) * L.block_size + center_coord(vi[k], L.voxel_size);
     off[k] = (pos[k] - c0) * L.voxel_size_inv;
   }
+  // the 8 neighbours: at most 8 blocks, one per corner of the 2x2x2 cell; resolve the (up to 7) other blocks first, then issue
+  // all 16 voxel loads independently of each other (the early-outs of a straight transcription serialise them)
+  u32 pools[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int mx = (c >> 2) & 1, my = (c >> 1) & 1, mz = c & 1;
+    const bool need = (!mx || vi[0] == 15) && (!my || vi[1] == 15) && (!mz || vi[2] == 15);  // this block combination is touched
+    u32 pool = base_pool;
+    if (c != 0) {
+      pool = kInvalid;
+      if (need) {
+        const u32 slot = ht_find(L.ht_keys, L.ht_mask, pack_key(b[0] + mx, b[1] + my, b[2] + mz));
+        if (slot != kInvalid) pool = L.ht_vals[slot];
+      }
+    }
+    pools[c] = pool;
+  }
+  float wv[8];
+  bool all_blocks = true;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     int v[3] = {vi[0] + ((i >> 2) & 1), vi[1] + ((i >> 1) & 1), vi[2] + (i & 1)};
-    int nb[3] = {b[0], b[1], b[2]};
-    bool moved = false;
+    int sel = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (v[k] >= 16) {
-        nb[k]++;
         v[k] -= 16;
-        moved = true;
+        sel |= 4 >> k;
       }
-    u32 pool = base_pool;
-    if (moved) {
-      const u32 slot = ht_find(L.ht_keys, L.ht_mask, pack_key(nb[0], nb[1], nb[2]));
-      if (slot == kInvalid) return o;
-      pool = L.ht_vals[slot];
-      if (pool == kInvalid) return o;
-    }
-    const u32* vox = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + static_cast<u32>(v[0] + 16 * (v[1] + 16 * v[2]))) * kWordsPerVoxel;
+    const u32 pool = pools[sel];
+    all_blocks = all_blocks && pool != kInvalid;
+    const u32 safe = pool == kInvalid ? base_pool : pool;
+    const u32* vox = L.voxels + (static_cast<size_t>(safe) * kVoxelsPerBlock + static_cast<u32>(v[0] + 16 * (v[1] + 16 * v[2]))) * kWordsPerVoxel;
     d[i] = __uint_as_float(vox[0]);
-    const float w = __uint_as_float(vox[1]);
-    if (!(w > 0.0f)) return o;  // Interpolator<TsdfVoxel>::isVoxelValid
+    wv[i] = __uint_as_float(vox[1]);
   }
+  if (!all_blocks) return o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (!(wv[i] > 0.0f)) return o;  // Interpolator<TsdfVoxel>::isVoxelValid
   float md[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -230,7 +246,8 @@ __global__ void __launch_bounds__(256) k_reg_scale(double* __restrict__ a, size_
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, RelPose P, const float* __restrict__ pts, const u32* __restrict__ sample_idx,
-                                                               u32 n_res, double no_corr_cost, double* __restrict__ partials /*[grid][256]*/) {
+                                                               u32 n_res, double no_corr_cost, double* partials /*[grid][256]*/, double* __restrict__ out /*[256]*/,
+                                                               u32* ticket) {
   __shared__ double X[kRegThreads / 64][16][68];  // per wave: 16 components x 64 points (rows padded to 68: conflict-free writes, 2-way reads)
   __shared__ double tile[kRegThreads / 64][256];
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -270,11 +287,30 @@ __global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, Re
   __syncthreads();
   partials[static_cast<size_t>(blockIdx.x) * kPartial + threadIdx.x] =
       ((tile[0][threadIdx.x] + tile[1][threadIdx.x]) + tile[2][threadIdx.x]) + tile[3][threadIdx.x];
-}
-__global__ void __launch_bounds__(256) k_reg_reduce_partials(const double* __restrict__ partials, u32 nb, double* __restrict__ out /*[256]*/) {
-  double s = 0.0;
-  for (u32 b = 0; b < nb; ++b) s += partials[static_cast<size_t>(b) * kPartial + threadIdx.x];
-  out[threadIdx.x] = s;
+  // the workgroup that finishes last sums the partials of all workgroups in workgroup order: same bits every run, and no
+  // second launch (the one-workgroup reduction kernel took longer than this kernel)
+  __shared__ u32 last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(ticket, 1u);
+    last = (t == gridDim.x - 1u) ? 1u : 0u;
+    if (last) *ticket = 0u;  // ready for the next launch on this stream
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains; the order of the additions stays fixed
+  const u32 nb = gridDim.x;
+  u32 bq = 0;
+  for (; bq + 4 <= nb; bq += 4) {
+    s0 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq) * kPartial + threadIdx.x]);
+    s1 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq + 1) * kPartial + threadIdx.x]);
+    s2 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq + 2) * kPartial + threadIdx.x]);
+    s3 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq + 3) * kPartial + threadIdx.x]);
+  }
+  for (; bq < nb; ++bq) s0 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq) * kPartial + threadIdx.x]);
+  out[threadIdx.x] = (s0 + s1) + (s2 + s3);
 }
 
 // ---- WeightedSampler<RegistrationPoint>::getRandomItem, reproducible and on the device ---------------------------------
@@ -353,6 +389,7 @@ struct cox_reg {
   u64 pending_n = 0;
   double *d_res = nullptr, *d_jf = nullptr, *d_jr = nullptr;
   u64 res_cap = 0, jf_cap = 0, jr_cap = 0;
+  u32* d_ticket = nullptr;    // last-workgroup ticket of the fused reduction (zero between launches)
   double* d_small = nullptr;  // block sums / partials / results
   u64 small_cap = 0;
   double* h_small = nullptr;  // pinned, 256 + 2 doubles
@@ -520,6 +557,8 @@ int cox_reg_create(const cox_regpoints_t* reference, const cox_layer_t* reading,
   bool ok = hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&G->h_small), sizeof(double) * 258, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipEventCreate(&G->ev0) == hipSuccess && hipEventCreate(&G->ev1) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&G->d_ticket), sizeof(u32)) == hipSuccess && hipMemset(G->d_ticket, 0, sizeof(u32)) == hipSuccess &&
+       hipDeviceSynchronize() == hipSuccess;
   if (!ok) {
     cox_reg_destroy(G);
     return COX_ERR_NO_DEVICE;
@@ -531,7 +570,7 @@ void cox_reg_destroy(cox_reg_t* G) {
   if (!G) return;
   (void)hipSetDevice(G->reading->device);
   if (G->stream) (void)hipStreamSynchronize(G->stream);
-  void* ptrs[] = {G->d_idx, G->d_stored, G->d_res, G->d_jf, G->d_jr, G->d_small};
+  void* ptrs[] = {G->d_idx, G->d_stored, G->d_res, G->d_jf, G->d_jr, G->d_small, G->d_ticket};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (G->h_small) (void)hipHostFree(G->h_small);
@@ -644,7 +683,7 @@ int cox_reg_normal_eq_begin(cox_reg_t* G, const double pose_ref[4], const double
   const u32* d_idx;
   COX_TRY(stage_samples(G, sample_idx, n_res, &d_idx));
   const u32 n = static_cast<u32>(n_res);
-  // enough workgroups to fill 256 CUs a few times over, but no more than the work needs
+  // one workgroup per 256 residuals up to 1024 workgroups (then they stride); the last one to finish reduces
   const u32 nb = std::min<u32>(1024, (n + kRegThreads - 1) / kRegThreads);
   COX_TRY(dev_grow(&G->d_small, &G->small_cap, static_cast<u64>(nb) * kPartial + kPartial));
   const RelPose P = make_rel_pose(pose_ref, pose_read);
@@ -652,8 +691,7 @@ int cox_reg_normal_eq_begin(cox_reg_t* G, const double pose_ref[4], const double
   cox_layer_wait_writes(G->reading, s);  // frames still in flight on the reading layer
   COX_HIP(hipEventRecord(G->ev0, s));
   hipLaunchKernelGGL(k_reg_normal_eq, dim3(nb), dim3(kRegThreads), 0, s, reading_view(G->reading), P, G->ref->pts, d_idx, n, G->no_corr_cost,
-                     G->d_small + kPartial);
-  hipLaunchKernelGGL(k_reg_reduce_partials, dim3(1), dim3(256), 0, s, G->d_small + kPartial, nb, G->d_small);
+                     G->d_small + kPartial, G->d_small, G->d_ticket);
   COX_HIP(hipEventRecord(G->ev1, s));
   COX_HIP(hipMemcpyAsync(G->h_small, G->d_small, sizeof(double) * kPartial, hipMemcpyDeviceToHost, s));
   G->pending = true;
