@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--pcie-frames", type=int, default=100, help="frames of the PCIe-inclusive legs (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--serial", action="store_true", help="sync after every frame (profiling aid: kernel times without cross-frame overlap)")
+    ap.add_argument("--no-ramp", action="store_true", help="no untimed clock-ramp frames (PMC passes: every dispatch of the run then belongs to warmup + steps frames)")
     return ap.parse_args()
 
 
@@ -162,6 +163,8 @@ def main():
     def clock_ramp(method, seconds=0.3):
         """Untimed extra frames on a scratch layer so that the timed region starts at running clocks (the reported `warmup`
         frames still go through the measured layer)."""
+        if args.no_ramp:
+            return
         scratch = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
         si = Integrator(eng, scratch, cfg, method)
         t0 = time.perf_counter()

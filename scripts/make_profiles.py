@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Assemble profiles/rNN_* from one collection run on the GPU box (see profiles/README.md for the commands).
+"""Assemble profiles/rNN_* from one collection run on the GPU box (scripts/collect_profiles.sh; see profiles/README.md).
 
-    python scripts/make_profiles.py gpurun_out/r r01
+    python scripts/make_profiles.py gpurun_out/r2prof r02
 """
 import collections
 import csv
+import glob
 import json
 import os
 import subprocess
@@ -14,6 +15,16 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 HERE = os.path.dirname(os.path.abspath(__file__))
+COMMON = "--cpu-frames 0 --reg-iters 8 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
+FRAMES_TRACE = 320   # warmup 20 + steps 300
+FRAMES_PMC = 80      # --warmup 20 --steps 60 --no-ramp
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {suffix} under {src}/{sub}")
+    return hits[0]
 
 
 def run(*a):
@@ -24,18 +35,21 @@ def copy(a, b):
     open(b, "w").write(open(a).read())
 
 
-CMD = "python bench.py --cpu-frames 0 --reg-iters 8 --fast-frames 0 --no-profile-pass"
-for sub, pre, name, head in (
-        ("async", "a", "bench", f"# rocprofv3 --kernel-trace --stats -- {CMD}   (merged, 320 frames, frames overlapped on two streams)"),
-        ("serial", "s", "bench_serial", f"# rocprofv3 --kernel-trace --stats -- {CMD} --serial   (one frame in flight)"),
-        ("fast", "f", "bench_fast", "# rocprofv3 --kernel-trace --stats -- python bench.py --method fast --cpu-frames 0 --reg-iters 8 --no-profile-pass   (320 frames)")):
-    stats = os.path.join(src, sub, f"{pre}_kernel_stats.csv")
-    copy(stats, os.path.join(P, f"{tag}_{name}_kernel_stats.csv"))
-    open(os.path.join(P, f"{tag}_{name}_kernel_stats.txt"), "w").write(head + "\n" + run(os.path.join(HERE, "kstats.py"), stats, "320"))
-open(os.path.join(P, f"{tag}_timeline_concurrency.txt"), "w").write(
-    f"# kernels in flight during the middle half of the fusion frames of: rocprofv3 --kernel-trace -- {CMD}\n" +
-    run(os.path.join(HERE, "timeline.py"), os.path.join(src, "async", "a_kernel_trace.csv")))
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
 copy(os.path.join(src, "bench_line.json"), os.path.join(P, f"{tag}_bench_line.json"))
+for m in ("merged", "fast"):
+    for mode, flag, what in (("async", "", "frames overlapped as in the timed run"), ("serial", " --serial", "one frame in flight")):
+        stats = find(f"{m}_{mode}", "kernel_stats.csv")
+        name = f"{tag}_bench_{m}{'_serial' if mode == 'serial' else ''}_kernel_stats"
+        copy(stats, os.path.join(P, name + ".csv"))
+        head = f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --method {m} {COMMON}{flag}   ({what}; us/frame = total / {FRAMES_TRACE} frames: 20 warm-up + 300 timed)"
+        open(os.path.join(P, name + ".txt"), "w").write(head + "\n" + run(os.path.join(HERE, "kstats.py"), stats, str(FRAMES_TRACE)))
+try:
+    open(os.path.join(P, f"{tag}_timeline_concurrency.txt"), "w").write(
+        f"# kernels in flight during the middle half of the fusion frames of: rocprofv3 --kernel-trace -- python3 bench.py --method merged {COMMON}\n" +
+        run(os.path.join(HERE, "timeline.py"), find("merged_async", "kernel_trace.csv")))
+except Exception as e:  # the timeline is a nice-to-have
+    print("timeline skipped:", e)
 
 
 def pmc(path, name):
@@ -48,20 +62,31 @@ def pmc(path, name):
             order.append(k)
         acc[k] += float(r["Counter_Value"])
         cnt[k] += 1
-    return {k: acc[k] / cnt[k] for k in order}, order
+    return acc, cnt, order
 
 
-PMC_CMD = "python bench.py --serial --steps 60 --warmup 20 --cpu-frames 0 --reg-iters 0 --fast-frames 0 --no-profile-pass --no-events"
-f, order = pmc(os.path.join(src, "pmc_fetch", "p_counter_collection.csv"), "FETCH_SIZE")
-w, _ = pmc(os.path.join(src, "pmc_write", "p_counter_collection.csv"), "WRITE_SIZE")
-lines = [f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another pass) -- {PMC_CMD}; mean per launch, KB",
-         f"{'kernel':46s} {'FETCH_SIZE':>12s} {'WRITE_SIZE':>12s}"]
-lines += [f"{k[:46]:46s} {f[k]:12.0f} {w.get(k, float('nan')):12.0f}" for k in order]
-open(os.path.join(P, f"{tag}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
-json.dump({"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- {PMC_CMD}; mean per launch",
-           "unit": "bytes",
-           "note": "raw counter x 1024 (KB); FETCH_SIZE is NOT doubled: the gfx950 half-count applies to 16-B/lane streaming reads, these "
-                   "kernels gather 4-12 B/lane (uncalibrated, MI355X_MICROARCH.md HBM section)",
-           "kernels": {k: {"fetch_bytes": f[k] * 1024, "write_bytes": w.get(k, 0.0) * 1024} for k in order}},
-          open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-print("profiles written for", tag)
+for m in ("merged", "fast"):
+    cmd = f"python3 bench.py --method {m} --serial --steps 60 --warmup 20 --cpu-frames 0 --reg-iters 0 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-events --no-ramp"
+    f, fc, order = pmc(find(f"{m}_pmc_fetch", "counter_collection.csv"), "FETCH_SIZE")
+    w, wc, _ = pmc(find(f"{m}_pmc_write", "counter_collection.csv"), "WRITE_SIZE")
+    lines = [f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another pass) -- {cmd}",
+             f"# per kernel: launches per frame, KB per launch (raw counter), MB per frame; {FRAMES_PMC} frames",
+             f"{'kernel':46s} {'launch/frame':>12s} {'FETCH KB':>10s} {'WRITE KB':>10s} {'MB/frame':>9s}"]
+    total, launches = 0.0, 0.0
+    per_kernel = {}
+    for k in order:
+        lf = fc[k] / FRAMES_PMC
+        fk, wk = f[k] / fc[k], (w.get(k, 0.0) / wc[k] if wc.get(k) else 0.0)
+        mb = (f[k] + w.get(k, 0.0)) * 1024 / FRAMES_PMC / 1e6
+        total += mb
+        launches += lf
+        per_kernel[k] = {"launches_per_frame": lf, "fetch_bytes_per_launch": fk * 1024, "write_bytes_per_launch": wk * 1024, "bytes_per_frame": mb * 1e6}
+        lines.append(f"{k[:46]:46s} {lf:12.2f} {fk:10.0f} {wk:10.0f} {mb:9.2f}")
+    lines.append(f"{'TOTAL':46s} {launches:12.2f} {'':>10s} {'':>10s} {total:9.2f}")
+    open(os.path.join(P, f"{tag}_pmc_traffic_{m}.txt"), "w").write("\n".join(lines) + "\n")
+    json.dump({"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- {cmd}",
+               "commit": commit, "frames": FRAMES_PMC, "unit": "bytes", "bytes_per_frame": total * 1e6, "launches_per_frame": launches,
+               "note": "sum over ALL kernels of the run of (FETCH_SIZE + WRITE_SIZE) x 1024 / frames (raw counters in KB); FETCH_SIZE is NOT doubled: the gfx950 "
+                       "half-count applies to 16-B/lane streaming reads, these kernels gather 4-12 B/lane (uncalibrated, MI355X_MICROARCH.md HBM section)",
+               "kernels": per_kernel}, open(os.path.join(P, f"{tag}_pmc_traffic_{m}.json"), "w"), indent=1)
+print("profiles written for", tag, "commit", commit)
