@@ -17,7 +17,7 @@ P = os.path.join(ROOT, "profiles")
 HERE = os.path.dirname(os.path.abspath(__file__))
 COMMON = "--cpu-frames 0 --reg-iters 8 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
 FRAMES_TRACE = 320   # warmup 20 + steps 300
-FRAMES_PMC = 80      # --warmup 20 --steps 60 --no-ramp
+FRAMES_PMC = 40      # the last 40 of the 80 frames (--warmup 20 --steps 60 --no-ramp): steady state
 
 
 def find(sub, suffix):
@@ -52,11 +52,19 @@ except Exception as e:  # the timeline is a nice-to-have
     print("timeline skipped:", e)
 
 
+STEADY = 40  # frames of the PMC run that are counted: the last 40 (set-up -- a 1.6 GB pool memset, the first frames' block allocations -- stays out)
+
+
 def pmc(path, name):
+    """Per kernel: summed counter and dispatch count over the LAST `STEADY` frames of the run.  A frame ends with its
+    k_apply_long dispatch (exactly one per frame, the last kernel of a frame in --serial mode)."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_apply_long")]
+    assert len(ends) >= STEADY + 1, len(ends)
+    lo, hi = ends[-STEADY - 1] + 1, ends[-1] + 1
     acc, cnt, order = collections.defaultdict(float), collections.defaultdict(int), []
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != name:
-            continue
+    for r in rows[lo:hi]:
         k = r["Kernel_Name"].split("(")[0]
         if k not in acc:
             order.append(k)
@@ -86,7 +94,7 @@ for m in ("merged", "fast"):
     open(os.path.join(P, f"{tag}_pmc_traffic_{m}.txt"), "w").write("\n".join(lines) + "\n")
     json.dump({"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- {cmd}",
                "commit": commit, "frames": FRAMES_PMC, "unit": "bytes", "bytes_per_frame": total * 1e6, "launches_per_frame": launches,
-               "note": "sum over ALL kernels of the run of (FETCH_SIZE + WRITE_SIZE) x 1024 / frames (raw counters in KB); FETCH_SIZE is NOT doubled: the gfx950 "
+               "note": "sum over ALL kernels dispatched during the last 40 frames of the run of (FETCH_SIZE + WRITE_SIZE) x 1024 / 40 (raw counters in KB; set-up such as the 1.6 GB pool memset stays out); FETCH_SIZE is NOT doubled: the gfx950 "
                        "half-count applies to 16-B/lane streaming reads, these kernels gather 4-12 B/lane (uncalibrated, MI355X_MICROARCH.md HBM section)",
                "kernels": per_kernel}, open(os.path.join(P, f"{tag}_pmc_traffic_{m}.json"), "w"), indent=1)
 print("profiles written for", tag, "commit", commit)
