@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "cox_internal.hpp"
@@ -226,6 +227,7 @@ __global__ void __launch_bounds__(256) k_bundle_keys(const FrameParams* __restri
     while ((1u << (bits - 1)) < np2) ++bits;
     sort_info->nbits = bits;
     sort_info->parity = 0;
+    sort_info->base = 0;
   }
   if (seq >= n) return;
   const u32 slot = pslot[mixed_index(seq, n)];  // the bundling sort starts from visiting order: gather on the read side
@@ -538,7 +540,7 @@ __device__ __forceinline__ void fill_ord_info(const LayerView& L, const u32* __r
 // width the record sort needs.
 __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ rec_key, u32* __restrict__ rec_ray, u32 rec_cap,
                                               Counters* cnt, SortInfo* sort_info, const u64* __restrict__ fh_keys, u32 fh_mask, const u32* __restrict__ touched_slots,
-                                              int4* __restrict__ ord_info) {
+                                              int4* __restrict__ ord_info, int by_block) {
   const FrameParams P = *Pp;
   const u32 n_slots = cnt->n_ray_slots;
   fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
@@ -547,8 +549,9 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
     const bool overflow = cnt->n_records > rec_cap;
-    sort_info->nbits = overflow ? 0u : bits;  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : (by_block ? bits - 12u : bits);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
+    sort_info->base = by_block ? 12u : 0u;  // block apply: a stable partition by block ordinal is all the global order it needs
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (cnt->n_records > rec_cap) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -782,7 +785,8 @@ __global__ void __launch_bounds__(256) k_touch_wave(const FrameParams* __restric
 
 __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const u32* __restrict__ path_in, u32* __restrict__ rec_key,
                                                    u32* __restrict__ rec_ray, u32 rec_cap, Counters* cnt, SortInfo* sort_info,
-                                                   const u64* __restrict__ fh_keys, u32 fh_mask, const u32* __restrict__ touched_slots, int4* __restrict__ ord_info) {
+                                                   const u64* __restrict__ fh_keys, u32 fh_mask, const u32* __restrict__ touched_slots, int4* __restrict__ ord_info,
+                                                   int by_block) {
   const FrameParams P = *Pp;
   const u32 n_slots = uniform_u32(cnt->n_ray_slots);
   fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
@@ -791,8 +795,9 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : bits;  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : (by_block ? bits - 12u : bits);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
+    sort_info->base = by_block ? 12u : 0u;
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (overflow) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -1209,6 +1214,245 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
   }
 }
 
+// ---- block apply: the TSDF update with the 16^3 block staged in LDS ------------------------------------------------------
+// The records arrive PARTITIONED by block (one stable radix pass on the block-ordinal bits; ray order inside a block is
+// preserved).  One workgroup owns one touched block:
+//   0. the block (48 KB, wire words) is read into LDS with full-line loads;
+//   1. every record of the block is evaluated once (voxel centre, sdf, update weight) and classified: a SATURATING record
+//      (saturating_update: provably leaves distance == truncation, adds an integer weight) only needs its weight summed --
+//      per voxel, in LDS, with integer atomics (exact in any order); any other record marks its voxel "dirty";
+//   2. per voxel: if no record was dirty and the voxel sits at +truncation with an integer weight (or is unobserved), its whole
+//      run folds to  w <- min(max_weight, w + sum)  -- bit-identical to replaying it (exactness
+//      arguments) -- which is most of a frame: the free space in front of the surfaces;
+//   3. the records of the remaining ("hard") voxels -- the surface band -- are compacted in ray order, batches of 2048 are
+//      sorted by voxel in LDS (stable counting sort: wave match-any ranks), and every hard voxel replays its records in
+//      order with the reference's updateTsdfVoxel; the voxel state lives in LDS across batches;
+//   4. the block goes back to HBM with full-line stores.
+// No float atomics; the result is the single-threaded reference order, bit for bit.  This replaces two of the three global
+// sort passes of the record pipeline and the 12-B scatter / gather of the per-record apply kernels.
+constexpr u32 kHardBatch = 2048;
+
+__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ blk_beg, u32* __restrict__ blk_end, const Counters* cnt) {
+  const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
+  const u32* __restrict__ key = V.key[V.info->parity & 1u];
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 k = key[i];
+    if (k == kInvalid) continue;
+    const u32 ord = k >> 12;
+    if (i == 0 || (key[i - 1] >> 12) != ord) blk_beg[ord] = i;
+    if (i + 1 == n || (key[i + 1] >> 12) != ord) blk_end[ord] = i + 1;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
+                                                     u32* __restrict__ blk_beg, u32* __restrict__ blk_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
+  const FrameParams P = *Pp;
+  __shared__ u32 blk[kVoxelsPerBlock * kWordsPerVoxel];
+  __shared__ u32 acc_sum[kVoxelsPerBlock];  // phases 1-2: sum of the saturating weights of a voxel; phase 3: end of the voxel's run in the sorted batch
+  __shared__ u32 acc_cnt[kVoxelsPerBlock];  // phases 1-2: records of the voxel | dirty << 31; phase 3: records of the voxel in the batch
+  __shared__ u32 hardbits[kVoxelsPerBlock / 32];
+  __shared__ float b_sdf[kHardBatch], b_uw[kHardBatch];
+  __shared__ u32 b_col[kHardBatch];
+  __shared__ unsigned short b_lin[kHardBatch], perm[kHardBatch];
+  __shared__ u32 wsum[4], scan_lds[4], any_hard_s;
+  // last kernel of the frame: make this frame's error bits sticky until the host next looks, and leave the layer's block
+  // count where the host can read it without a sync (pinned word; it decides when to grow the pool)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (cnt->err) atomicOr(layer_err, cnt->err);
+    *h_nblocks = min(*L.d_nblocks, L.capacity);
+  }
+  const u32 n_touched = (cnt->err & kErrRecords) ? 0u : cnt->n_touched;
+  const u32 par = V.info->parity & 1u;
+  const u32* __restrict__ rec_key = V.key[par];
+  const u32* __restrict__ rec_ray = V.ray[par];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool exact_cap = P.max_weight <= 16711680.0f;  // 2^24 - 2^16: w + u never leaves the exact integers before the cap applies
+  u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
+  for (u32 ord = blockIdx.x; ord < n_touched; ord += gridDim.x) {
+    const u32 beg = blk_beg[ord], end = blk_end[ord];
+    __syncthreads();  // everybody has read its range (and is done with the previous block's LDS)
+    if (tid == 0) {
+      blk_beg[ord] = 0;  // leave the tables empty for the next frame
+      blk_end[ord] = 0;
+      any_hard_s = 0;
+    }
+    const int4 info = ord_info[ord];
+    const u32 pool = static_cast<u32>(info.w);
+    if (end <= beg || pool == kInvalid) continue;  // (uniform)
+    u32* gblk = L.voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
+    for (u32 i = tid; i < kVoxelsPerBlock * kWordsPerVoxel; i += 256) blk[i] = gblk[i];
+    for (u32 v = tid; v < kVoxelsPerBlock; v += 256) {
+      acc_sum[v] = 0;
+      acc_cnt[v] = 0;
+    }
+    __syncthreads();
+    // ---- 1. classify --------------------------------------------------------------------------------------------------
+    for (u32 i = beg + tid; i < end; i += 256) {
+      const u32 lin = rec_key[i] & 4095u, r = rec_ray[i];
+      const F3 pg{R.px[r], R.py[r], R.pz[r]};
+      const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), info.z + static_cast<int>(lin >> 8));
+      const float uw = update_weight(P, sdf, R.w[r]);
+      bool fold = foldable_update(P, sdf, uw);
+      if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
+      atomicAdd(&acc_cnt[lin], 1u);
+      if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
+    }
+    __syncthreads();
+    // ---- 2. fold what folds -------------------------------------------------------------------------------------------
+    bool any_hard = false;
+#pragma unroll 1
+    for (u32 q = 0; q < kVoxelsPerBlock / 256; ++q) {
+      const u32 v = q * 256 + tid;
+      const u32 c = acc_cnt[v], count = c & 0x7FFFFFFFu;
+      bool hard = false;
+      if (count) {
+        my_updates += count;
+        my_voxels += 1;
+        my_maxrun = max(my_maxrun, count);
+        const float d = __uint_as_float(blk[3 * v]), w = __uint_as_float(blk[3 * v + 1]);
+        const u32 sum = acc_sum[v];
+        hard = true;
+        if (!(c >> 31) && sum < (1u << 30) && (w == 0.0f || d == P.trunc)) {
+          if (w >= P.max_weight) {
+            hard = false;  // min(max_weight, w + u) == max_weight for every u > 0: nothing changes
+          } else if (w == truncf(w) && w >= 0.0f) {
+            const unsigned long long total = static_cast<unsigned long long>(w) + sum;
+            if (total < 16777216ull || exact_cap) {
+              const float nw = (static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u) >= P.max_weight) ? P.max_weight
+                                                                                                                                 : static_cast<float>(static_cast<u32>(total));
+              blk[3 * v] = __float_as_uint(P.trunc);  // an unobserved voxel's first saturating update sets the distance to +truncation
+              blk[3 * v + 1] = __float_as_uint(nw);
+              hard = false;
+            }
+          }
+        }
+      }
+      const u64 hm = __ballot(hard);
+      if (lane == 0) {
+        hardbits[(q * 256 + wave * 64) >> 5] = static_cast<u32>(hm);
+        hardbits[((q * 256 + wave * 64) >> 5) + 1] = static_cast<u32>(hm >> 32);
+      }
+      any_hard = any_hard || hm != 0ull;
+    }
+    if (any_hard && lane == 0) any_hard_s = 1;
+    __syncthreads();
+    // ---- 3. the hard voxels: ordered replay ---------------------------------------------------------------------------
+    if (any_hard_s) {
+      u32 fill = 0;
+      for (u32 base = beg;; base += 256) {
+        const bool done = base >= end;
+        if (done || fill + 256 > kHardBatch) {
+          // -- flush: sort the batch by voxel (stable), replay every voxel's run in order
+          if (fill) {
+            for (u32 v = tid; v < kVoxelsPerBlock; v += 256) acc_cnt[v] = 0;
+            __syncthreads();
+            for (u32 p = tid; p < fill; p += 256) atomicAdd(&acc_cnt[b_lin[p]], 1u);
+            __syncthreads();
+            {  // exclusive scan over the 4096 voxels; thread t owns voxels [16 t, 16 t + 16)
+              u32 loc[16], s = 0;
+#pragma unroll
+              for (u32 k = 0; k < 16; ++k) {
+                loc[k] = acc_cnt[tid * 16 + k];
+                s += loc[k];
+              }
+              u32 tot;
+              u32 run = block_exclusive_scan<4>(s, &tot, scan_lds);
+#pragma unroll
+              for (u32 k = 0; k < 16; ++k) {
+                acc_sum[tid * 16 + k] = run;
+                run += loc[k];
+              }
+            }
+            __syncthreads();
+            const u32 chunk = ((fill + 255u) / 256u) * 64u;  // positions per wave, a multiple of 64
+            for (u32 w = 0; w < 4; ++w) {
+              if (wave == w) {
+                const u32 wbeg = min(fill, w * chunk), wend = min(fill, wbeg + chunk);
+                for (u32 p0 = wbeg; p0 < wend; p0 += 64) {
+                  const u32 p = p0 + lane;
+                  const bool valid = p < wend;
+                  const u32 lin = valid ? b_lin[p] : 0u;
+                  u64 peers = __ballot(valid);
+#pragma unroll
+                  for (int b = 0; b < 12; ++b) {
+                    const bool bit = (lin >> b) & 1u;
+                    const u64 m = __ballot(bit);
+                    peers &= bit ? m : ~m;
+                  }
+                  const u64 lower = peers & ((1ull << lane) - 1ull);
+                  if (valid) perm[acc_sum[lin] + static_cast<u32>(__popcll(lower))] = static_cast<unsigned short>(p);
+                  wave_lds_handover();
+                  if (valid && lower == 0ull) acc_sum[lin] += static_cast<u32>(__popcll(peers));
+                  wave_lds_handover();
+                }
+              }
+              __syncthreads();
+            }
+#pragma unroll 1
+            for (u32 k = 0; k < 16; ++k) {
+              const u32 v = tid * 16 + k;
+              const u32 c = acc_cnt[v];
+              if (!c) continue;
+              const u32 e = acc_sum[v];
+              Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
+              for (u32 j = e - c; j < e; ++j) {
+                const u32 idx = perm[j];
+                update_voxel(P, vx, b_sdf[idx], b_uw[idx], b_col[idx]);
+              }
+              blk[3 * v] = __float_as_uint(vx.d);
+              blk[3 * v + 1] = __float_as_uint(vx.w);
+              blk[3 * v + 2] = vx.c;
+            }
+            __syncthreads();
+            fill = 0;
+          }
+          if (done) break;
+        }
+        // -- one round: 256 consecutive records, the hard ones appended to the batch in order
+        const u32 i = base + tid;
+        bool keep = false;
+        u32 lin = 0, r = 0;
+        if (i < end) {
+          lin = rec_key[i] & 4095u;
+          r = rec_ray[i];
+          keep = (hardbits[lin >> 5] >> (lin & 31u)) & 1u;
+        }
+        const u64 m = __ballot(keep);
+        if (lane == 0) wsum[wave] = static_cast<u32>(__popcll(m));
+        __syncthreads();
+        u32 pos = fill + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
+        for (u32 w = 0; w < wave; ++w) pos += wsum[w];
+        if (keep) {
+          const F3 pg{R.px[r], R.py[r], R.pz[r]};
+          const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), info.z + static_cast<int>(lin >> 8));
+          b_lin[pos] = static_cast<unsigned short>(lin);
+          b_sdf[pos] = sdf;
+          b_uw[pos] = update_weight(P, sdf, R.w[r]);
+          b_col[pos] = R.color[r];
+        }
+        fill += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+      }
+    }
+    // ---- 4. the block goes back ---------------------------------------------------------------------------------------
+    __syncthreads();
+    for (u32 i = tid; i < kVoxelsPerBlock * kWordsPerVoxel; i += 256) gblk[i] = blk[i];
+  }
+  // statistics
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    my_updates += __shfl_xor(my_updates, off, 64);
+    my_voxels += __shfl_xor(my_voxels, off, 64);
+    my_maxrun = max(my_maxrun, static_cast<u32>(__shfl_xor(static_cast<int>(my_maxrun), off, 64)));
+  }
+  if (lane == 0 && my_voxels) {
+    u32* sh = cnt->shard[(blockIdx.x * 4u + wave) & 63u];
+    atomicAdd(&sh[kShUpdates], my_updates);
+    atomicAdd(&sh[kShVoxels], my_voxels);
+    atomicMax(&sh[kShMaxRun], my_maxrun);
+  }
+}
+
 // ---- depth front end ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_depth_flags(const float* __restrict__ depth, u32 n, u32* __restrict__ flag) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1307,6 +1551,7 @@ struct RecordSet {  // lives B1 .. B2
   u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
   u32* touched_slots = nullptr;  // [layer ht_cap]
   int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
+  u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap] record range of every touched block (block apply); zero between frames
   SortInfo* sort_info = nullptr;
   hipEvent_t done = nullptr;  // B2 of the frame that used this set
   bool used = false;
@@ -1346,6 +1591,7 @@ struct cox_integrator {
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
   bool small_axis_cap = false;  // no ray can cross more than kAxisCapSmall - 2 planes of one axis
   u32 layer_generation = 0;     // cox_layer::generation the layer-sized buffers (touched_slots, ord_info, graphs) belong to
+  bool block_apply = true;      // records partitioned by block + k_apply_block; COX_APPLY=records selects the per-record kernels (full sort)
   // ordering against the caller's stream (cox_integrator_set_input_stream): the first stage waits for what the producer has
   // enqueued, and the producer's stream waits until the engine has read the inputs (stream-ordered allocators may then
   // recycle them)
@@ -1687,19 +1933,20 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
       hipLaunchKernelGGL(k_touch_wave<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
                          I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? 1 : 0);
   } else {
     hipLaunchKernelGGL(k_touch, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, F.cnt, I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? 1 : 0);
   }
   delete t_walk;
   TimedRegion t_sort(I, COX_KC_RECORD_SORT, s);
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
   // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
   // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
-  (void)radix_sort_pairs<12>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true, 3,
-                             I->sort_rec, S.sort_info, s);
+  // Block apply: only the block-ordinal bits are sorted (a stable partition; one pass up to 4095 touched blocks, two beyond).
+  (void)radix_sort_pairs<12>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true,
+                             I->block_apply ? 2 : 3, I->sort_rec, S.sort_info, s);
   return COX_OK;
 }
 static int stage_b2(const StageCtx& c, hipStream_t s) {
@@ -1709,6 +1956,12 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &F.cnt->n_records};
   TimedRegion t(I, COX_KC_APPLY, s);
+  if (I->block_apply) {
+    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt);
+    hipLaunchKernelGGL(k_apply_block, dim3(1024), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
+                       I->layer->h_nblocks);
+    return COX_OK;
+  }
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
   hipLaunchKernelGGL(k_apply_long, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt,
                      I->layer->d_err, I->layer->h_nblocks);
@@ -1875,6 +2128,11 @@ static int follow_layer(cox_integrator* I) {
     for (RecordSet& S : I->rs) {
       COX_TRY(dev_realloc(&S.touched_slots, Lh->ht_cap));
       COX_TRY(dev_realloc(&S.ord_info, Lh->ht_cap));
+      COX_TRY(dev_realloc(&S.blk_beg, Lh->ht_cap));
+      COX_TRY(dev_realloc(&S.blk_end, Lh->ht_cap));
+      COX_HIP(hipMemset(S.blk_beg, 0, sizeof(u32) * Lh->ht_cap));
+      COX_HIP(hipMemset(S.blk_end, 0, sizeof(u32) * Lh->ht_cap));
+      COX_HIP(hipDeviceSynchronize());
     }
     I->layer_generation = Lh->generation;
   }
@@ -2050,6 +2308,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   I->method = method;
   // stage graphs: measured slightly slower than eager launches here (2 936 vs 3 117 frames/s), so opt-in
   I->use_graphs = std::getenv("COX_GRAPH") != nullptr && std::getenv("COX_NO_GRAPH") == nullptr;
+  I->block_apply = !(std::getenv("COX_APPLY") && std::string(std::getenv("COX_APPLY")) == "records");
   int st = COX_OK;
   auto ev = [&](hipEvent_t* e) {
     if (st == COX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
@@ -2092,6 +2351,10 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     ev(&S.done);
     if (st == COX_OK) st = dev_realloc(&S.touched_slots, layer->ht_cap);  // one entry per block key the table can hold
     if (st == COX_OK) st = dev_realloc(&S.ord_info, layer->ht_cap);
+    if (st == COX_OK) st = dev_realloc(&S.blk_beg, layer->ht_cap);
+    if (st == COX_OK) st = dev_realloc(&S.blk_end, layer->ht_cap);
+    if (st == COX_OK && (hipMemset(S.blk_beg, 0, sizeof(u32) * layer->ht_cap) != hipSuccess || hipMemset(S.blk_end, 0, sizeof(u32) * layer->ht_cap) != hipSuccess))
+      st = COX_ERR_NO_DEVICE;
     info(&S.sort_info);
   }
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
@@ -2175,6 +2438,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (RecordSet& S : I->rs) {
     for (void* p : {static_cast<void*>(S.rec_key[0]), static_cast<void*>(S.rec_key[1]), static_cast<void*>(S.rec_ray[0]), static_cast<void*>(S.rec_ray[1]),
                     static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots), static_cast<void*>(S.ord_info),
+                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end),
                     static_cast<void*>(S.sort_info)})
       ptrs.push_back(p);
     events.push_back(S.done);

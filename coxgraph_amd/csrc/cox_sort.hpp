@@ -138,6 +138,8 @@ __device__ __forceinline__ u32 rs_tile_shift(u32 n) {
 struct SortInfo {
   u32 nbits;   // key bits to sort on (passes whose shift >= nbits do nothing)
   u32 parity;  // 0: result in buffer 0, 1: result in buffer 1 (written by the kernels)
+  u32 base;    // the nbits bits start at this bit of the key (a stable partition by the key's upper part); 0 = whole key
+  u32 pad;
 };
 
 // Digit layout of one sort: the nbits key bits are split evenly over ceil(nbits / RB) passes (23 bits with RB = 12 ->
@@ -163,6 +165,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ 
   int shift;
   u32 bits;
   if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
+  if (host_bits < 0) shift += static_cast<int>(info->base);
   const u32 kDigits = 1u << bits;
   const u32* keys = (pass & 1) ? k1 : k0;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(kRsOffThreads) k_rs_offsets(const u32* __restr
   int shift;
   u32 bits;
   if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
+  if (host_bits < 0) shift += static_cast<int>(info->base);
   const u32 kDigits = 1u << bits;
   if (blockIdx.x * 64u >= kDigits) return;  // the grid covers 2^RB digits
   constexpr u32 kWaves = kRsOffThreads / 64;
@@ -260,6 +264,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
   int shift;
   u32 bits;
   if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
+  if (host_bits < 0) shift += static_cast<int>(info->base);
   const u32 kDigits = 1u << bits;
   // the digit totals of this pass were consumed by the offsets kernel: leave them zero for the next sort (no memset per sort)
   if (blockIdx.x == 0)
