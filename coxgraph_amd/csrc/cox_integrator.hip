@@ -549,9 +549,9 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
     const bool overflow = cnt->n_records > rec_cap;
-    sort_info->nbits = overflow ? 0u : (by_block ? bits - 12u : bits);  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : (by_block ? bits - 8u : bits);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = by_block ? 12u : 0u;  // block apply: a stable partition by block ordinal is all the global order it needs
+    sort_info->base = by_block ? 8u : 0u;  // block apply: a stable partition by tile (block ordinal, z slab) is all the global order it needs
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (cnt->n_records > rec_cap) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -795,9 +795,9 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : (by_block ? bits - 12u : bits);  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : (by_block ? bits - 8u : bits);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = by_block ? 12u : 0u;
+    sort_info->base = by_block ? 8u : 0u;
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (overflow) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -1214,95 +1214,112 @@ __global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restric
   }
 }
 
-// ---- block apply: the TSDF update with the 16^3 block staged in LDS ------------------------------------------------------
-// The records arrive PARTITIONED by block (one stable radix pass on the block-ordinal bits; ray order inside a block is
-// preserved).  One workgroup owns one touched block:
-//   0. the block (48 KB, wire words) is read into LDS with full-line loads;
-//   1. every record of the block is evaluated once (voxel centre, sdf, update weight) and classified: a SATURATING record
+// ---- block apply: the TSDF update with the voxel tiles staged in LDS -----------------------------------------------------
+// The records arrive PARTITIONED by tile = (block ordinal, z-slab of the block: 16 x 16 x 1 voxels = 256 voxels, 3 KB of
+// contiguous wire words) -- one or two stable radix passes on those bits; ray order inside a tile is preserved.  One
+// workgroup owns one tile (a 16^3 block is sixteen of them; a frame at 5 cm has ~10^3 tiles with records, at 1 cm ~10^5,
+// so the chip is full at every voxel size, and the near-camera blocks that every ray crosses are spread over 16 workgroups):
+//   0. the tile's voxels are read into LDS with full-line loads;
+//   1. every record of the tile is evaluated once (voxel centre, sdf, update weight) and classified: a SATURATING record
 //      (saturating_update: provably leaves distance == truncation, adds an integer weight) only needs its weight summed --
 //      per voxel, in LDS, with integer atomics (exact in any order); any other record marks its voxel "dirty";
 //   2. per voxel: if no record was dirty and the voxel sits at +truncation with an integer weight (or is unobserved), its whole
 //      run folds to  w <- min(max_weight, w + sum)  -- bit-identical to replaying it (exactness
 //      arguments) -- which is most of a frame: the free space in front of the surfaces;
-//   3. the records of the remaining ("hard") voxels -- the surface band -- are compacted in ray order, batches of 2048 are
+//   3. the records of the remaining ("hard") voxels -- the surface band -- are compacted in ray order, batches of 1024 are
 //      sorted by voxel in LDS (stable counting sort: wave match-any ranks), and every hard voxel replays its records in
 //      order with the reference's updateTsdfVoxel; the voxel state lives in LDS across batches;
-//   4. the block goes back to HBM with full-line stores.
-// No float atomics; the result is the single-threaded reference order, bit for bit.  This replaces two of the three global
+//   4. the tile goes back to HBM with full-line stores.
+// No float atomics; the result is the single-threaded reference order, bit for bit.  This replaces one or two of the global
 // sort passes of the record pipeline and the 12-B scatter / gather of the per-record apply kernels.
-constexpr u32 kHardBatch = 2048;
+constexpr u32 kSlabBits = 4;                               // z bits of the linear voxel index that belong to the tile id
+constexpr u32 kTileShift = 12 - kSlabBits;                 // tile id = voxel id >> kTileShift = block ordinal << 4 | z
+constexpr u32 kTileVox = 1u << kTileShift;                 // 256 voxels per tile
+constexpr u32 kTilesPerBlock = 1u << kSlabBits;
+constexpr u32 kHardBatch = 1024;
+constexpr u32 kBT = 256, kBW = kBT / 64;
 
-__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ blk_beg, u32* __restrict__ blk_end, const Counters* cnt) {
+__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, const Counters* cnt) {
   const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
   const u32* __restrict__ key = V.key[V.info->parity & 1u];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u32 k = key[i];
     if (k == kInvalid) continue;
-    const u32 ord = k >> 12;
-    if (i == 0 || (key[i - 1] >> 12) != ord) blk_beg[ord] = i;
-    if (i + 1 == n || (key[i + 1] >> 12) != ord) blk_end[ord] = i + 1;
+    const u32 t = k >> kTileShift;
+    if (i == 0 || (key[i - 1] >> kTileShift) != t) tile_beg[t] = i;
+    if (i + 1 == n || (key[i + 1] >> kTileShift) != t) tile_end[t] = i + 1;
   }
 }
 
-__global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
-                                                     u32* __restrict__ blk_beg, u32* __restrict__ blk_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
+__global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
+                                                     u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
   const FrameParams P = *Pp;
-  __shared__ u32 blk[kVoxelsPerBlock * kWordsPerVoxel];
-  __shared__ u32 acc_sum[kVoxelsPerBlock];  // phases 1-2: sum of the saturating weights of a voxel; phase 3: end of the voxel's run in the sorted batch
-  __shared__ u32 acc_cnt[kVoxelsPerBlock];  // phases 1-2: records of the voxel | dirty << 31; phase 3: records of the voxel in the batch
-  __shared__ u32 hardbits[kVoxelsPerBlock / 32];
+  __shared__ u32 blk[kTileVox * kWordsPerVoxel];
+  __shared__ u32 acc_sum[kTileVox];  // phases 1-2: sum of the saturating weights of a voxel; phase 3: end of the voxel's run in the sorted batch
+  __shared__ u32 acc_cnt[kTileVox];  // phases 1-2: records of the voxel | dirty << 31; phase 3: records of the voxel in the batch
+  __shared__ u32 hardbits[kTileVox / 32];
   __shared__ float b_sdf[kHardBatch], b_uw[kHardBatch];
   __shared__ u32 b_col[kHardBatch];
   __shared__ unsigned short b_lin[kHardBatch], perm[kHardBatch];
-  __shared__ u32 wsum[4], scan_lds[4], any_hard_s;
+  __shared__ u32 wsum[kBW], scan_lds[kBW], any_hard_s;
   // last kernel of the frame: make this frame's error bits sticky until the host next looks, and leave the layer's block
   // count where the host can read it without a sync (pinned word; it decides when to grow the pool)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (cnt->err) atomicOr(layer_err, cnt->err);
     *h_nblocks = min(*L.d_nblocks, L.capacity);
   }
-  const u32 n_touched = (cnt->err & kErrRecords) ? 0u : cnt->n_touched;
+  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTilesPerBlock;
   const u32 par = V.info->parity & 1u;
   const u32* __restrict__ rec_key = V.key[par];
   const u32* __restrict__ rec_ray = V.ray[par];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const bool exact_cap = P.max_weight <= 16711680.0f;  // 2^24 - 2^16: w + u never leaves the exact integers before the cap applies
   u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
-  for (u32 ord = blockIdx.x; ord < n_touched; ord += gridDim.x) {
-    const u32 beg = blk_beg[ord], end = blk_end[ord];
-    __syncthreads();  // everybody has read its range (and is done with the previous block's LDS)
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const u32 beg = tile_beg[tile], end = tile_end[tile];
+    if (end <= beg) continue;  // (uniform) no record touches this slab of the block
+    __syncthreads();           // everybody has read its range and is done with the previous tile's LDS
     if (tid == 0) {
-      blk_beg[ord] = 0;  // leave the tables empty for the next frame
-      blk_end[ord] = 0;
+      tile_beg[tile] = 0;  // leave the tables empty for the next frame
+      tile_end[tile] = 0;
       any_hard_s = 0;
     }
-    const int4 info = ord_info[ord];
+    const int4 info = ord_info[tile >> kSlabBits];
     const u32 pool = static_cast<u32>(info.w);
-    if (end <= beg || pool == kInvalid) continue;  // (uniform)
-    u32* gblk = L.voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
-    for (u32 i = tid; i < kVoxelsPerBlock * kWordsPerVoxel; i += 256) blk[i] = gblk[i];
-    for (u32 v = tid; v < kVoxelsPerBlock; v += 256) {
+    if (pool == kInvalid) continue;  // (uniform; such a block's records carry invalid keys anyway)
+    const int gz = info.z + static_cast<int>(tile & (kTilesPerBlock - 1u));
+    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTilesPerBlock - 1u)) * kTileVox) * kWordsPerVoxel;
+    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kBT) blk[i] = gblk[i];
+    for (u32 v = tid; v < kTileVox; v += kBT) {
       acc_sum[v] = 0;
       acc_cnt[v] = 0;
     }
     __syncthreads();
     // ---- 1. classify --------------------------------------------------------------------------------------------------
-    for (u32 i = beg + tid; i < end; i += 256) {
-      const u32 lin = rec_key[i] & 4095u, r = rec_ray[i];
-      const F3 pg{R.px[r], R.py[r], R.pz[r]};
-      const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), info.z + static_cast<int>(lin >> 8));
-      const float uw = update_weight(P, sdf, R.w[r]);
-      bool fold = foldable_update(P, sdf, uw);
-      if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
-      atomicAdd(&acc_cnt[lin], 1u);
-      if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
+    for (u32 i0 = beg + tid; i0 < end; i0 += 2 * kBT) {  // two records per thread in flight: the gathers are latency-bound
+      const u32 i1 = i0 + kBT;
+      const bool has1 = i1 < end;
+      const u32 k0 = rec_key[i0], r0 = rec_ray[i0];
+      const u32 k1 = has1 ? rec_key[i1] : 0u, r1 = has1 ? rec_ray[i1] : r0;
+      const F3 pg0{R.px[r0], R.py[r0], R.pz[r0]}, pg1{R.px[r1], R.py[r1], R.pz[r1]};
+      const float rw0 = R.w[r0], rw1 = R.w[r1];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !has1) break;
+        const u32 lin = (u ? k1 : k0) & (kTileVox - 1u);
+        const F3 pg = u ? pg1 : pg0;
+        const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+        const float uw = update_weight(P, sdf, u ? rw1 : rw0);
+        bool fold = foldable_update(P, sdf, uw);
+        if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
+        atomicAdd(&acc_cnt[lin], 1u);
+        if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
+      }
     }
     __syncthreads();
-    // ---- 2. fold what folds -------------------------------------------------------------------------------------------
-    bool any_hard = false;
-#pragma unroll 1
-    for (u32 q = 0; q < kVoxelsPerBlock / 256; ++q) {
-      const u32 v = q * 256 + tid;
+    // ---- 2. fold what folds (thread = voxel) ----------------------------------------------------------------------------
+    {
+      const u32 v = tid;
       const u32 c = acc_cnt[v], count = c & 0x7FFFFFFFu;
       bool hard = false;
       if (count) {
@@ -1318,10 +1335,9 @@ __global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restri
           } else if (w == truncf(w) && w >= 0.0f) {
             const unsigned long long total = static_cast<unsigned long long>(w) + sum;
             if (total < 16777216ull || exact_cap) {
-              const float nw = (static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u) >= P.max_weight) ? P.max_weight
-                                                                                                                                 : static_cast<float>(static_cast<u32>(total));
+              const float ft = static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u);
               blk[3 * v] = __float_as_uint(P.trunc);  // an unobserved voxel's first saturating update sets the distance to +truncation
-              blk[3 * v + 1] = __float_as_uint(nw);
+              blk[3 * v + 1] = __float_as_uint(ft >= P.max_weight ? P.max_weight : ft);
               hard = false;
             }
           }
@@ -1329,52 +1345,41 @@ __global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restri
       }
       const u64 hm = __ballot(hard);
       if (lane == 0) {
-        hardbits[(q * 256 + wave * 64) >> 5] = static_cast<u32>(hm);
-        hardbits[((q * 256 + wave * 64) >> 5) + 1] = static_cast<u32>(hm >> 32);
+        hardbits[wave * 2] = static_cast<u32>(hm);
+        hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
+        if (hm) any_hard_s = 1;
       }
-      any_hard = any_hard || hm != 0ull;
     }
-    if (any_hard && lane == 0) any_hard_s = 1;
     __syncthreads();
     // ---- 3. the hard voxels: ordered replay ---------------------------------------------------------------------------
     if (any_hard_s) {
       u32 fill = 0;
-      for (u32 base = beg;; base += 256) {
+      for (u32 base = beg;; base += kBT) {
         const bool done = base >= end;
-        if (done || fill + 256 > kHardBatch) {
+        if (done || fill + kBT > kHardBatch) {
           // -- flush: sort the batch by voxel (stable), replay every voxel's run in order
           if (fill) {
-            for (u32 v = tid; v < kVoxelsPerBlock; v += 256) acc_cnt[v] = 0;
+            acc_cnt[tid] = 0;
             __syncthreads();
-            for (u32 p = tid; p < fill; p += 256) atomicAdd(&acc_cnt[b_lin[p]], 1u);
+            for (u32 p = tid; p < fill; p += kBT) atomicAdd(&acc_cnt[b_lin[p] & (kTileVox - 1u)], 1u);
             __syncthreads();
-            {  // exclusive scan over the 4096 voxels; thread t owns voxels [16 t, 16 t + 16)
-              u32 loc[16], s = 0;
-#pragma unroll
-              for (u32 k = 0; k < 16; ++k) {
-                loc[k] = acc_cnt[tid * 16 + k];
-                s += loc[k];
-              }
+            {  // exclusive scan over the tile's voxels (thread = voxel)
+              const u32 c = acc_cnt[tid];
               u32 tot;
-              u32 run = block_exclusive_scan<4>(s, &tot, scan_lds);
-#pragma unroll
-              for (u32 k = 0; k < 16; ++k) {
-                acc_sum[tid * 16 + k] = run;
-                run += loc[k];
-              }
+              acc_sum[tid] = block_exclusive_scan<kBW>(c, &tot, scan_lds);
             }
             __syncthreads();
-            const u32 chunk = ((fill + 255u) / 256u) * 64u;  // positions per wave, a multiple of 64
-            for (u32 w = 0; w < 4; ++w) {
+            const u32 chunk = ((fill + kBT - 1u) / kBT) * 64u;  // positions per wave, a multiple of 64
+            for (u32 w = 0; w < kBW; ++w) {
               if (wave == w) {
                 const u32 wbeg = min(fill, w * chunk), wend = min(fill, wbeg + chunk);
                 for (u32 p0 = wbeg; p0 < wend; p0 += 64) {
                   const u32 p = p0 + lane;
                   const bool valid = p < wend;
-                  const u32 lin = valid ? b_lin[p] : 0u;
+                  const u32 lin = valid ? (b_lin[p] & (kTileVox - 1u)) : 0u;
                   u64 peers = __ballot(valid);
 #pragma unroll
-                  for (int b = 0; b < 12; ++b) {
+                  for (u32 b = 0; b < kTileShift; ++b) {
                     const bool bit = (lin >> b) & 1u;
                     const u64 m = __ballot(bit);
                     peers &= bit ? m : ~m;
@@ -1388,33 +1393,39 @@ __global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restri
               }
               __syncthreads();
             }
-#pragma unroll 1
-            for (u32 k = 0; k < 16; ++k) {
-              const u32 v = tid * 16 + k;
+            {
+              const u32 v = tid;
               const u32 c = acc_cnt[v];
-              if (!c) continue;
-              const u32 e = acc_sum[v];
-              Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
-              for (u32 j = e - c; j < e; ++j) {
-                const u32 idx = perm[j];
-                update_voxel(P, vx, b_sdf[idx], b_uw[idx], b_col[idx]);
+              if (c) {
+                const u32 e = acc_sum[v];
+                Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
+                for (u32 j = e - c; j < e; ++j) {
+                  const u32 idx = perm[j];
+                  const float uw = b_uw[idx];
+                  // a saturating record on a voxel that sits at +truncation only adds its weight: exactly what updateTsdfVoxel
+                  // computes there (distance provably stays == truncation -- saturating_update -- and the weight is the same
+                  // float addition), without its divisions: most records of a dirty voxel's run
+                  if ((b_lin[idx] & 0x8000u) && vx.d == P.trunc)
+                    vx.w = std_min(P.max_weight, vx.w + uw);
+                  else
+                    update_voxel(P, vx, b_sdf[idx], uw, b_col[idx]);
+                }
+                blk[3 * v] = __float_as_uint(vx.d);
+                blk[3 * v + 1] = __float_as_uint(vx.w);
+                blk[3 * v + 2] = vx.c;
               }
-              blk[3 * v] = __float_as_uint(vx.d);
-              blk[3 * v + 1] = __float_as_uint(vx.w);
-              blk[3 * v + 2] = vx.c;
             }
             __syncthreads();
             fill = 0;
           }
           if (done) break;
         }
-        // -- one round: 256 consecutive records, the hard ones appended to the batch in order
+        // -- one round: kBT consecutive records, the hard ones appended to the batch in order
         const u32 i = base + tid;
         bool keep = false;
-        u32 lin = 0, r = 0;
+        u32 lin = 0;
         if (i < end) {
-          lin = rec_key[i] & 4095u;
-          r = rec_ray[i];
+          lin = rec_key[i] & (kTileVox - 1u);
           keep = (hardbits[lin >> 5] >> (lin & 31u)) & 1u;
         }
         const u64 m = __ballot(keep);
@@ -1423,20 +1434,23 @@ __global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restri
         u32 pos = fill + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
         for (u32 w = 0; w < wave; ++w) pos += wsum[w];
         if (keep) {
+          const u32 r = rec_ray[i];
           const F3 pg{R.px[r], R.py[r], R.pz[r]};
-          const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), info.z + static_cast<int>(lin >> 8));
-          b_lin[pos] = static_cast<unsigned short>(lin);
+          const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+          const float uw = update_weight(P, sdf, R.w[r]);
+          b_lin[pos] = static_cast<unsigned short>(lin | (foldable_update(P, sdf, uw) ? 0x8000u : 0u));
           b_sdf[pos] = sdf;
-          b_uw[pos] = update_weight(P, sdf, R.w[r]);
+          b_uw[pos] = uw;
           b_col[pos] = R.color[r];
         }
-        fill += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+        for (u32 w = 0; w < kBW; ++w) fill += wsum[w];
         __syncthreads();
       }
     }
-    // ---- 4. the block goes back ---------------------------------------------------------------------------------------
+    // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
     __syncthreads();
-    for (u32 i = tid; i < kVoxelsPerBlock * kWordsPerVoxel; i += 256) gblk[i] = blk[i];
+    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kBT) gblk[i] = blk[i];
   }
   // statistics
 #pragma unroll
@@ -1446,7 +1460,7 @@ __global__ void __launch_bounds__(256) k_apply_block(const FrameParams* __restri
     my_maxrun = max(my_maxrun, static_cast<u32>(__shfl_xor(static_cast<int>(my_maxrun), off, 64)));
   }
   if (lane == 0 && my_voxels) {
-    u32* sh = cnt->shard[(blockIdx.x * 4u + wave) & 63u];
+    u32* sh = cnt->shard[(blockIdx.x * kBW + wave) & 63u];
     atomicAdd(&sh[kShUpdates], my_updates);
     atomicAdd(&sh[kShVoxels], my_voxels);
     atomicMax(&sh[kShMaxRun], my_maxrun);
@@ -1551,7 +1565,7 @@ struct RecordSet {  // lives B1 .. B2
   u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
   u32* touched_slots = nullptr;  // [layer ht_cap]
   int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
-  u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap] record range of every touched block (block apply); zero between frames
+  u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap * 16] record range of every tile (block apply); zero between frames
   SortInfo* sort_info = nullptr;
   hipEvent_t done = nullptr;  // B2 of the frame that used this set
   bool used = false;
@@ -1944,7 +1958,8 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
   // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
   // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
-  // Block apply: only the block-ordinal bits are sorted (a stable partition; one pass up to 4095 touched blocks, two beyond).
+  // Block apply: only the tile bits (block ordinal, z slab) are sorted -- a stable partition; one pass up to 255 touched
+  // blocks (the 5 cm frames), two beyond.
   (void)radix_sort_pairs<12>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true,
                              I->block_apply ? 2 : 3, I->sort_rec, S.sort_info, s);
   return COX_OK;
@@ -1958,7 +1973,7 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   TimedRegion t(I, COX_KC_APPLY, s);
   if (I->block_apply) {
     hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt);
-    hipLaunchKernelGGL(k_apply_block, dim3(1024), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
+    hipLaunchKernelGGL(k_apply_block, dim3(8192), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
                        I->layer->h_nblocks);
     return COX_OK;
   }
@@ -2128,10 +2143,10 @@ static int follow_layer(cox_integrator* I) {
     for (RecordSet& S : I->rs) {
       COX_TRY(dev_realloc(&S.touched_slots, Lh->ht_cap));
       COX_TRY(dev_realloc(&S.ord_info, Lh->ht_cap));
-      COX_TRY(dev_realloc(&S.blk_beg, Lh->ht_cap));
-      COX_TRY(dev_realloc(&S.blk_end, Lh->ht_cap));
-      COX_HIP(hipMemset(S.blk_beg, 0, sizeof(u32) * Lh->ht_cap));
-      COX_HIP(hipMemset(S.blk_end, 0, sizeof(u32) * Lh->ht_cap));
+      COX_TRY(dev_realloc(&S.blk_beg, static_cast<size_t>(Lh->ht_cap) * kTilesPerBlock));
+      COX_TRY(dev_realloc(&S.blk_end, static_cast<size_t>(Lh->ht_cap) * kTilesPerBlock));
+      COX_HIP(hipMemset(S.blk_beg, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
+      COX_HIP(hipMemset(S.blk_end, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
       COX_HIP(hipDeviceSynchronize());
     }
     I->layer_generation = Lh->generation;
@@ -2351,9 +2366,10 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     ev(&S.done);
     if (st == COX_OK) st = dev_realloc(&S.touched_slots, layer->ht_cap);  // one entry per block key the table can hold
     if (st == COX_OK) st = dev_realloc(&S.ord_info, layer->ht_cap);
-    if (st == COX_OK) st = dev_realloc(&S.blk_beg, layer->ht_cap);
-    if (st == COX_OK) st = dev_realloc(&S.blk_end, layer->ht_cap);
-    if (st == COX_OK && (hipMemset(S.blk_beg, 0, sizeof(u32) * layer->ht_cap) != hipSuccess || hipMemset(S.blk_end, 0, sizeof(u32) * layer->ht_cap) != hipSuccess))
+    if (st == COX_OK) st = dev_realloc(&S.blk_beg, static_cast<size_t>(layer->ht_cap) * kTilesPerBlock);
+    if (st == COX_OK) st = dev_realloc(&S.blk_end, static_cast<size_t>(layer->ht_cap) * kTilesPerBlock);
+    if (st == COX_OK && (hipMemset(S.blk_beg, 0, sizeof(u32) * layer->ht_cap * kTilesPerBlock) != hipSuccess ||
+                         hipMemset(S.blk_end, 0, sizeof(u32) * layer->ht_cap * kTilesPerBlock) != hipSuccess))
       st = COX_ERR_NO_DEVICE;
     info(&S.sort_info);
   }
