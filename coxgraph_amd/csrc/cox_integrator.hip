@@ -1616,8 +1616,8 @@ struct cox_integrator {
   uint8_t* own_rgba = nullptr;
   u32* depth_flag = nullptr;
   u32* d_depth_n = nullptr;  // point count of the depth front end
-  SortWorkspace sort_pts, sort_rec;
-  ScanWorkspace scanws_a, scanws_b, scanws_d;
+  SortWorkspace sort_pts, sort_rec, sort_vis;  // sort_vis: the fast integrator's visit sort (runs beside the previous frame's record sort)
+  ScanWorkspace scanws_a, scanws_b, scanws_d, scanws_f;
   u32 scan_cap = 0;
   Counters* h_ring = nullptr;  // pinned, kStatRing entries
   uint64_t frame_no = 0;       // frames enqueued
@@ -1743,6 +1743,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   }
   COX_TRY(alloc_sort_ws(&I->sort_rec, rcap));
   if (I->method == COX_METHOD_FAST) {
+    COX_TRY(alloc_sort_ws(&I->sort_vis, rcap));
     FastState& X = I->fast;
     COX_TRY(dev_realloc(&X.fhash, cap));
     COX_TRY(dev_realloc(&X.fresh, cap));
@@ -1764,6 +1765,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&I->scanws_a.block_sums, need_scan));
     COX_TRY(dev_realloc(&I->scanws_b.block_sums, need_scan));
     COX_TRY(dev_realloc(&I->scanws_d.block_sums, need_scan));
+    COX_TRY(dev_realloc(&I->scanws_f.block_sums, need_scan));
     I->scan_cap = need_scan;
   }
   I->rcap = rcap;
@@ -2017,7 +2019,7 @@ static int run_stage(int k, const StageCtx& c) {
 
 // ---- fast: one frame.  Everything runs on one stream; the relaxation of the early-termination rule (cox_fast.hpp) is
 // checked for convergence from the host every few sweeps, so unlike simple / merged this call is not fully asynchronous.
-static int fast_frame(const StageCtx& c, hipStream_t s) {
+static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   BundleSet& B = *c.B;
@@ -2063,7 +2065,7 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   for (int round = 0;; ++round) {
     // candidate visits: the first cap[r] voxels of every ray's walk, sorted by slot of the observed set
     t_fast = new TimedRegion(I, COX_KC_FAST_VISITS, s);
-    exclusive_scan_u32(X.cap, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_b, s);
+    exclusive_scan_u32(X.cap, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_f, s);
     if (I->small_axis_cap)
       hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
                          X.cap, round == 0 ? 1 : 0, vcap, F.cnt);
@@ -2071,7 +2073,7 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
       hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
                          X.cap, round == 0 ? 1 : 0, vcap, F.cnt);
     const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21),
-                                        kFastSlotBits, false, 2, I->sort_rec, nullptr, s);
+                                        kFastSlotBits, false, 2, I->sort_vis, nullptr, s);
     hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
     V = FastVisits{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
     delete t_fast;
@@ -2119,9 +2121,13 @@ static int fast_frame(const StageCtx& c, hipStream_t s) {
   const u32* reach = X.reach[sweep & 1];
   hipLaunchKernelGGL(k_fast_obs_commit, gv, dim3(256), 0, s, V, reach, X.eloc, X.tmax, X.table_obs, F.cnt, vcap);
   hipLaunchKernelGGL(k_fast_finish, gr, dim3(256), 0, s, F.rays, reach, F.cnt);
-  // updates: the record pipeline of `simple` (records sorted by voxel, replayed in visiting order)
-  COX_TRY(stage_b1(c, s));
-  COX_TRY(stage_b2(c, s));
+  // updates: the record pipeline of `simple` (records partitioned by tile, replayed in visiting order) -- on the second
+  // stream, so that the next frame's start set / visits / sweeps (which only touch the two tables and this frame's own
+  // buffers) run beside it
+  COX_HIP(hipEventRecord(I->ev_a2, s));
+  COX_HIP(hipStreamWaitEvent(s_back, I->ev_a2, 0));
+  COX_TRY(run_stage(2, c));  // stage_b1 on st[2] (== s_back); replayed as a captured graph when COX_GRAPH is set
+  COX_TRY(run_stage(3, c));  // stage_b2 on st[3] == st[2]
   return COX_OK;
 }
 
@@ -2179,14 +2185,21 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
     COX_HIP(hipStreamWaitEvent(I->st[0], I->ev_producer, 0));
   }
-  if (I->method == COX_METHOD_FAST) {  // single stream, see fast_frame
-    COX_TRY(fast_frame(ctx, I->st[0]));
+  if (I->method == COX_METHOD_FAST) {  // front (sets, sweeps) on st[0], record stage on st[2], see fast_frame
+    if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-4 is done with this frame set
+    if (S.used) COX_HIP(hipStreamWaitEvent(I->st[0], S.done, 0));  // frame t-2's record stage is done with this record set (the visit sort borrows it)
+    COX_TRY(fast_frame(ctx, I->st[0], I->st[2]));
     COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
-    COX_HIP(hipEventRecord(F.done, I->st[0]));
-    COX_HIP(hipEventRecord(Lh->last_write, I->st[0]));
+    if (I->has_producer) {  // the inputs are read by the front only
+      COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[0]));
+      COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
+    }
+    COX_HIP(hipEventRecord(F.done, I->st[2]));
+    COX_HIP(hipEventRecord(S.done, I->st[2]));
+    COX_HIP(hipEventRecord(Lh->last_write, I->st[2]));
     Lh->has_write = true;
-    if (I->has_producer) COX_HIP(hipStreamWaitEvent(I->producer, F.done, 0));  // the sweeps re-read nothing, but the record stage does
     F.used = true;
+    S.used = true;
     I->last_has_counts = true;
     COX_HIP(hipGetLastError());
     return COX_OK;
@@ -2331,10 +2344,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   // The hardware runs at most two of these kernels side by side (measured: profiles/), so two
   // streams (ray generation | layer update) give all the overlap there is; COX_STREAMS=4 puts every stage on its own.
   I->n_streams = (std::getenv("COX_STREAMS") && std::atoi(std::getenv("COX_STREAMS")) == 4) ? 4 : 2;
-  if (method == COX_METHOD_FAST) {
-    I->n_streams = 1;
-    I->use_graphs = false;
-  }
+  if (method == COX_METHOD_FAST) I->n_streams = 2;  // front | record stage (graphs, if enabled, cover the record stage only)
   for (int k = 0; k < 4; ++k) {
     if ((I->n_streams == 2 && (k & 1)) || (I->n_streams == 1 && k > 0)) {
       I->st[k] = I->st[k - 1];
@@ -2423,7 +2433,8 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     }
   for (hipEvent_t e : I->event_pool) (void)hipEventDestroy(e);
   std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
-                             I->sort_rec.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums};
+                             I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
+                             I->scanws_f.block_sums};
   {
     FastState& X = I->fast;
     for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
