@@ -86,3 +86,99 @@ def test_two_ranks_gloo(oracle):
     for k, v in single.items():
         assert np.allclose(v, res[0]["poses"][k], atol=1e-9), (k, v, res[0]["poses"][k])
     assert res[0]["summary"]["final_cost"] < 1e-4 * max(1.0, res[0]["summary"]["initial_cost"])
+
+
+# ---- the server's inter-robot leg (bench.py --gpus N, BASELINE configs[2] / [4]) over gloo ---------------------------------
+def _client_submap(eng, client, voxel=0.10):
+    """One client's finished submap (oracle): TSDF -> ESDF layer + isosurface registration points."""
+    from coxgraph_amd import synth
+    from coxgraph_amd.capi import Layer, Integrator, RegPoints
+    cfg = eng.default_config(**synth.integrator_overrides(voxel))
+    layer = Layer(eng, voxel)
+    integ = Integrator(eng, layer, cfg, "merged")
+    for t in range(0, 60, 10):
+        T, pts, rgba, _ = synth.make_frame(t, client=client, n_clients=12)   # 30 degrees apart: neighbours overlap
+        integ.integrate_points(T, pts[::6], rgba[::6])
+    esdf = layer.esdf(max_distance_m=2.0, min_distance_m=1.5 * voxel)
+    pts = RegPoints.from_isosurface(eng, layer, 1.0)
+    return esdf, pts
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from coxgraph_amd.capi import Engine, Layer, RegPoints, Registration
+    from coxgraph_amd.posegraph import PoseGraph, RegistrationConstraint
+    eng = Engine(os.path.join(ROOT, "oracle", "libcoxoracle.so"), "coxo_")
+    esdf, pts = _client_submap(eng, rank)
+    # exchange: wire arrays of the ESDF layer + the point set, padded to the largest rank, one all-gather each
+    idx, vox = esdf.download()
+    p = pts.download()
+    sizes = torch.tensor([idx.shape[0], p.shape[0]], dtype=torch.int64)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [tuple(int(v) for v in t.tolist()) for t in all_sizes]
+    max_nb, max_np = max(s[0] for s in all_sizes), max(s[1] for s in all_sizes)
+
+    def gather(a, n_max, tail, dtype):
+        buf = torch.zeros((n_max,) + tail, dtype=dtype)
+        buf[:a.shape[0]] = torch.from_numpy(a)
+        lst = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(lst, buf)
+        return [t.numpy() for t in lst]
+    g_idx = gather(idx, max_nb, (3,), torch.int32)
+    g_vox = gather(vox.view(np.int32), max_nb, (4096, 3), torch.int32)
+    g_pts = gather(p, max_np, (5,), torch.float32)
+    # constraints (a, b), a < b, dealt over the ranks: client a's points against client b's distance field
+    pairs = [(a, b) for a in range(world) for b in range(a + 1, world)]
+    pg = PoseGraph()
+    for k in range(world):
+        pg.add_node(k, [0.02 * k, -0.01 * k, 0.0, 0.002 * k], constant=(k == 0))
+    keep = []
+    for k, (a, b) in enumerate(pairs):
+        if k % world != rank:
+            pg.reg.append(None)
+            continue
+        lb = Layer(eng, 0.10)
+        lb.upload(g_idx[b][:all_sizes[b][0]], g_vox[b][:all_sizes[b][0]].view(np.uint32))
+        pa = RegPoints(eng, g_pts[a][:all_sizes[a][1]])
+        reg = Registration(eng, pa, lb)
+        reg.draw_samples(int(0.3 * pa.n), 1000 + k)
+        keep.append((lb, pa, reg))
+        pg.reg.append(RegistrationConstraint(a, b, reg))
+    poses = {k: v.copy() for k, v in pg.poses.items()}
+    cost, g, H, free = pg.build(poses, group=dist.group.WORLD)
+    out[rank] = dict(cost=float(cost), g=g.tolist(), H=H.tolist(), sizes=all_sizes)
+    dist.destroy_process_group()
+
+
+def test_submap_exchange_and_inter_robot_registration_over_gloo(oracle):
+    """Three ranks = three clients: every rank finishes its own submap, the submaps are all-gathered as wire arrays, each
+    constraint registers CLIENT a's isosurface points against CLIENT b's ESDF on the rank that owns it, one all-reduce sums
+    the packed normal equations -- every rank ends with the system a single process builds from all three submaps."""
+    from coxgraph_amd.capi import Registration
+    from coxgraph_amd.posegraph import PoseGraph, RegistrationConstraint
+    world = 3
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_exchange_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for r in range(1, world):
+        assert res[r]["cost"] == res[0]["cost"] and res[r]["H"] == res[0]["H"] and res[r]["g"] == res[0]["g"]
+    subs = [_client_submap(oracle, c) for c in range(world)]
+    assert [tuple(s) for s in res[0]["sizes"]] == [(e.stats()[0], p.n) for e, p in subs]
+    pg = PoseGraph()
+    for k in range(world):
+        pg.add_node(k, [0.02 * k, -0.01 * k, 0.0, 0.002 * k], constant=(k == 0))
+    keep = []
+    for k, (a, b) in enumerate([(a, b) for a in range(world) for b in range(a + 1, world)]):
+        reg = Registration(oracle, subs[a][1], subs[b][0])
+        reg.draw_samples(int(0.3 * subs[a][1].n), 1000 + k)
+        keep.append(reg)
+        pg.reg.append(RegistrationConstraint(a, b, reg))
+    cost, g, H, _ = pg.build({k: v.copy() for k, v in pg.poses.items()})
+    assert cost > 0 and np.count_nonzero(H) > 0      # neighbouring clients overlap: the constraints have correspondences
+    assert np.isclose(cost, res[0]["cost"], rtol=1e-12) and np.allclose(g, res[0]["g"], rtol=1e-10, atol=1e-12) and np.allclose(H, res[0]["H"], rtol=1e-10, atol=1e-12)
