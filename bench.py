@@ -189,6 +189,7 @@ def main():
             integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
         integ.sync()
         integ.class_times(reset=True)
+        integ.host_time(reset=True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -208,6 +209,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         live = integ.class_times() if timed_events else None
+        hms, hn = integ.host_time()
+        run_stream.host_ms_per_frame = hms / max(hn, 1)   # caller's thread inside the integrate calls (launch-rate bound at 5 cm)
         return layer, integ, dt, live
 
     def roofline_of(method, steps, live):
@@ -258,6 +261,7 @@ def main():
     # ---- headline ----------------------------------------------------------------------------------------------------
     layer, integ, dt, live = run_stream(args.method, args.steps, not args.no_events)
     fps = world * args.steps / dt
+    host_ms = run_stream.host_ms_per_frame
     roofline, frame_stats, crit, alg_bytes = (None, None, None, None)
     if rank == 0 and not args.no_profile_pass:
         roofline, frame_stats, crit, alg_bytes = roofline_of(args.method, args.steps, live)
@@ -470,6 +474,7 @@ def main():
                                    f"{args.method} integrator semantics (the reference's configured method is fast; bit-exact vs CPU oracle), points resident in HBM",
                        "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
             "frame_stats_mean": frame_stats,
+            "host_submit_ms_per_frame": host_ms,   # caller's thread inside cox_integrate_points_dev (the other half of a frame is enqueued by the integrator's submission thread)
             "critical_path": dict(crit, note="longest sequential chains of any timed frame: points of the largest bundle (merged), updates of the busiest voxel") if crit else None,
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": ({"merged": (fps if args.method == "merged" else (other or {}).get("merged", {}).get("value", 0.0)) / cpu["same_method"]["value"],

@@ -295,6 +295,12 @@ class Integrator:
         self.eng.check(self.eng.fn("integrator_class_times")(self.h, ms, n, C.c_int(int(reset))), "integrator_class_times")
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(self.KERNEL_CLASSES)}
 
+    def host_time(self, reset=False):
+        """(ms, frames): host time spent inside the integrate calls (enqueueing; cox_integrator_host_time)."""
+        ms, n = C.c_double(), C.c_uint64()
+        self.eng.check(self.eng.fn("integrator_host_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))), "integrator_host_time")
+        return float(ms.value), int(n.value)
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         self.eng.check(self.eng.fn("integrator_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))),

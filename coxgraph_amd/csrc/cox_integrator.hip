@@ -25,6 +25,13 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "cox_internal.hpp"
 #include "cox_sort.hpp"
@@ -47,6 +54,8 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 err;
   u32 n_depth_points;
   u32 n_sorted_valid;  // valid points as seen in the sorted bundling keys (merged)
+  u32 ticket_bounds;   // arrival counter of k_bundle_count (the last workgroup scans the tile counts)
+  u32 n_piece_slots;   // piece path: sum of the rays' piece bounds = slots of the piece arrays in use
   // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
   // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
   // [s][0] valid points, [s][1] updates, [s][2] voxels, [s][3] long runs, [s][4] rays
@@ -73,6 +82,9 @@ struct RayArrays {
   u64* key;                 // terminal voxel key (anti-grazing)
   u32* nsteps;              // records this ray emits
   u32* rec_off;             // exclusive scan of nsteps
+  float* q;                 // piece path: 8 floats per ray in one 32-B line: point_G - origin (x, y, z), its length, the ray's weight, 3 unused
+  u32* pbound;              // piece path: upper bound of the ray's piece count (piece_bound)
+  u32* piece_off;           // exclusive scan of pbound
 };
 
 // both ping-pong buffers of the record sort + where the result ended up
@@ -253,24 +265,76 @@ struct BundleView {
   const u32* val[2];
   const SortInfo* info;
 };
-__global__ void __launch_bounds__(256) k_bundle_heads(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ head) {
-  const u32 n = Pp->n_points;
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u32* __restrict__ skey = V.key[V.info->parity & 1u];
+// Bundle boundaries in two launches (round 1 used five: head flags, a three-kernel scan, starts).  A head is a sorted position
+// whose key differs from its predecessor's; a bundle's ordinal is the number of heads before it.
+//   k_bundle_count   per tile of 2048 positions: number of heads; the workgroup that arrives last scans the tile counts
+//                    (a frame has ~150 tiles) and publishes the number of bundles
+//   k_bundle_starts  per tile: heads again, in-tile exclusive scan, bstart[tile base + rank] = position
+constexpr u32 kBoundTile = 2048;
+__device__ __forceinline__ bool bundle_head(const u32* __restrict__ skey, u32 i, u32 n) {
+  if (i >= n) return false;
   const u32 k = skey[i];
-  head[i] = (k != kInvalid && (i == 0 || skey[i - 1] != k)) ? 1u : 0u;
+  return k != kInvalid && (i == 0 || skey[i - 1] != k);
 }
-__global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ head_scan, u32* __restrict__ bstart,
-                                                       Counters* cnt) {
+__global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ tile_sums, Counters* cnt) {
+  __shared__ u32 lds[16];
+  __shared__ u32 last;
   const u32 n = Pp->n_points;
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) cnt->n_ray_slots = cnt->n_rays;  // n_rays = number of bundles, written by the scan before this kernel
-  if (i >= n) return;
   const u32* __restrict__ skey = V.key[V.info->parity & 1u];
-  const u32 k = skey[i];
-  if (k != kInvalid && (i == 0 || skey[i - 1] != k)) bstart[head_scan[i]] = i;
-  if (k != kInvalid && (i + 1 == n || skey[i + 1] == kInvalid)) cnt->n_sorted_valid = i + 1;  // invalid keys sort last: one writer
+  const u32 n_tiles = (n + kBoundTile - 1) / kBoundTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    u32 c = 0;
+#pragma unroll
+    for (u32 q = 0; q < kBoundTile / 256; ++q) c += bundle_head(skey, tile * kBoundTile + q * 256 + threadIdx.x, n) ? 1u : 0u;
+    u32 tot;
+    (void)block_exclusive_scan<4>(c, &tot, lds);
+    if (threadIdx.x == 0) tile_sums[tile] = tot;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(&cnt->ticket_bounds, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  u32 carry = 0;
+  for (u32 base = 0; base < n_tiles; base += 256) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = (i < n_tiles) ? __hip_atomic_load(&tile_sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    u32 tot;
+    const u32 ex = block_exclusive_scan<4>(v, &tot, lds);
+    if (i < n_tiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    cnt->n_rays = carry;  // number of bundles
+    cnt->n_ray_slots = carry;
+  }
+}
+__global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ tile_base, u32* __restrict__ bstart,
+                                                       Counters* cnt) {
+  __shared__ u32 lds[4];
+  const u32 n = Pp->n_points;
+  const u32* __restrict__ skey = V.key[V.info->parity & 1u];
+  const u32 n_tiles = (n + kBoundTile - 1) / kBoundTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // thread t owns the 8 consecutive positions [tile * 2048 + 8 t, + 8)
+    const u32 i0 = tile * kBoundTile + threadIdx.x * 8;
+    bool h[8];
+    u32 c = 0;
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      h[q] = bundle_head(skey, i0 + q, n);
+      c += h[q] ? 1u : 0u;
+    }
+    u32 tot;
+    u32 rank = tile_base[tile] + block_exclusive_scan<4>(c, &tot, lds);
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      const u32 i = i0 + q;
+      if (h[q]) bstart[rank++] = i;
+      if (i < n && skey[i] != kInvalid && (i + 1 == n || skey[i + 1] == kInvalid)) cnt->n_sorted_valid = i + 1;  // invalid keys sort last: one writer
+    }
+  }
 }
 
 // two waves per bundle: the sequential weighted mean of its points in visiting order, bit-exact with the
@@ -285,7 +349,27 @@ __global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __rest
 // side by side on different SIMDs instead of back to back.  Skipped points (w < eps, or anything after the first
 // point of a clearing bundle) are the identity step: (M, A, D) = (1, 0, 1).
 typedef float MergeOp __attribute__((ext_vector_type(4)));  // (M, A, D, 1/D)
-__global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ bstart, RayArrays R, Counters* cnt) {
+
+// Piece path (k_touch_pieces): a PIECE is a maximal run of consecutive steps of one ray inside one tile (block, z slab:
+// 16 x 16 x 1 voxels) -- the voxel coordinates of a walk are monotone, so a ray meets a tile in one run of at most 31
+// steps.  Pieces are written at fixed slots (exclusive scan of this bound over the rays), which keeps them in ray order
+// without a sort key for it.  The wave walk starts a piece at every round of 64 steps, at every z step and at every
+// change of the x / y block; its per-axis step counts are at most n_axis + 1 (wave_ray_path generates n_axis + 2 crossing
+// times and rejects a walk that uses the last one).  Rays that are known here to take the sequential walk get the
+// trivial bound (one piece per step); the + 4 covers a ray whose walk is only found to need the fallback later (and the
+// sequential walk makes no round pieces) -- if even that is exceeded the frame is dropped and reported, never wrong.
+__device__ __forceinline__ u32 piece_bound(const Dda& d, u32 axis_cap) {
+  const u32 ns = d.nsteps;
+  if (ns == 0) return 0;
+  const u32 gen = ns + 1;
+  const u32 g0 = min(d.n_axis[0] + 2, gen), g1 = min(d.n_axis[1] + 2, gen), g2 = min(d.n_axis[2] + 2, gen);
+  if (d.sgn[0] == 0 || d.sgn[1] == 0 || d.sgn[2] == 0 || g0 > axis_cap || g1 > axis_cap || g2 > axis_cap || ns > 3 * axis_cap) return ns;
+  const u32 b = (ns + 63) / 64 + (d.n_axis[2] + 1) + ((d.n_axis[0] + 1) / 16 + 1) + ((d.n_axis[1] + 1) / 16 + 1) + 4;
+  return min(b, ns);
+}
+
+__global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ bstart, RayArrays R, Counters* cnt,
+                                                      u32 piece_axis_cap) {
   const FrameParams P = *Pp;
   const u32 np2 = P.np2;
   const float* __restrict__ xyz = P.xyz;
@@ -463,6 +547,15 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
         R.flags[m] = 1u | (clearing ? 2u : 0u);
         R.key[m] = key;
         R.nsteps[m] = d.nsteps;
+        if (piece_axis_cap) {
+          R.pbound[m] = piece_bound(d, piece_axis_cap);
+          // what compute_sdf derives from the ray alone, with its own operations, once per ray instead of once per step
+          const F3 dv = pg - F3{P.tx, P.ty, P.tz};
+          typedef float F4 __attribute__((ext_vector_type(4)));
+          F4* q = reinterpret_cast<F4*>(R.q + static_cast<size_t>(m) * 8u);
+          q[0] = F4{dv.x, dv.y, dv.z, sqrtf(dot3(dv, dv))};
+          q[1] = F4{W, 0.0f, 0.0f, 0.0f};
+        }
       }
     }
   }
@@ -688,12 +781,13 @@ __device__ __forceinline__ bool wave_ray_path(const Dda& d0, u32 ns, float* tl /
   return __ballot(bad) == 0ull;
 }
 
-__device__ __forceinline__ void touch_block(const FrameParams& P, const LayerView& L, u64 bkey, u32* touched_slots, Counters* cnt, u32* layer_err) {
+// returns the block's hash slot (kInvalid: table full)
+__device__ __forceinline__ u32 touch_block(const FrameParams& P, const LayerView& L, u64 bkey, u32* touched_slots, Counters* cnt, u32* layer_err) {
   bool fresh;
   const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
   if (slot == kInvalid) {
     atomicOr(layer_err, kErrTable);
-    return;
+    return kInvalid;
   }
   if (fresh) {
     const u32 pool = atomicAdd(L.d_nblocks, 1u);
@@ -713,6 +807,7 @@ __device__ __forceinline__ void touch_block(const FrameParams& P, const LayerVie
     touched_slots[ord] = slot;
     L.ht_ord[slot] = ord;
   }
+  return slot;
 }
 
 template <u32 kAxisCap>
@@ -873,6 +968,190 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
         rec_key[off + s] = vid;
         rec_ray[off + s] = r;
       }
+    }
+  }
+}
+
+// ---- piece path (merged, no anti-grazing): the walk is written once, as bytes, and partitioned by PIECES ---------------------
+// Instead of one (voxel id, ray) record per step -- 8 B written, sorted twice and read again -- the walk leaves
+//   one piece per (ray, tile) run (piece_bound), at slot piece_off[r] + k:  key = hash slot of the block << 4 | z & 15,
+//                                                 start = the slot itself,  raylen = ray << 5 | steps (<= 31), and
+//   lin8[32 * slot + j]    the voxel's (x & 15) | (y & 15) << 4 inside its tile for step j of the piece: one byte per step,
+//                          a piece's bytes in one aligned 32-B segment (eight lanes read a piece with one dword load each).
+// Only the pieces (a sixth to a tenth of the records) are sorted by tile; k_apply_pieces gathers each tile's steps through
+// them.  Slots of a ray's bound that it does not use carry the invalid key.
+struct PieceArrays {
+  u32* key;     // [piece slots]
+  u32* start;
+  u32* raylen;
+};
+constexpr u32 kPieceLenBits = 5;
+
+template <u32 kAxisCap>
+__global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ touched_slots, uint8_t* __restrict__ lin8,
+                                                      PieceArrays PA, u32 rec_cap, u32 piece_cap, Counters* cnt, u32* layer_err) {
+  const FrameParams P = *Pp;
+  __shared__ float lds_t[4][3 * kAxisCap];
+  __shared__ u32 lds_path[4][3 * kAxisCap];
+  const u32 n_slots = uniform_u32(cnt->n_ray_slots);
+  const bool overflow = uniform_u32(cnt->n_records) > rec_cap || uniform_u32(cnt->n_piece_slots) > piece_cap;  // frame dropped (k_piece_keys reports it)
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x >> 6;
+  float* tl = lds_t[wave];
+  u32* path = lds_path[wave];
+  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_slots; r += waves_total) {
+    const u32 ns = uniform_u32(R.nsteps[r]);
+    if (ns == 0) continue;
+    const bool clearing = (uniform_u32(R.flags[r]) & 2u) != 0;
+    const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
+    const u32 poff = uniform_u32(R.piece_off[r]), bound = uniform_u32(R.pbound[r]);
+    Dda d;
+    dda_setup(d, P, pg, clearing);
+    u32 pk = 0;  // pieces of this ray so far
+    if (wave_ray_path<kAxisCap>(d, ns, tl, path, lane)) {
+      u64 carry_key = kEmptyKey;
+      u32 carry_slot = kInvalid;
+      for (u32 base = 0; base < ns; base += 64) {
+        const u32 s = base + lane;
+        const bool act = s < ns;
+        u64 bkey = kEmptyKey;
+        u32 zs = 0, lin = 0;
+        if (act) {
+          const u32 p = path[s];
+          const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];
+          const int y = d.c[1] + static_cast<int>((p >> 10) & 1023u) * d.sgn[1];
+          const int z = d.c[2] + static_cast<int>(p >> 20) * d.sgn[2];
+          lin = static_cast<u32>((x & 15) | ((y & 15) << 4));
+          bkey = pack_key(x >> 4, y >> 4, z >> 4);
+          zs = static_cast<u32>(z & 15);
+        }
+        u64 prev_key = __shfl_up(bkey, 1, 64);
+        if (lane == 0) prev_key = carry_key;
+        const bool bhead = act && bkey != prev_key;
+        u32 slot = kInvalid;
+        if (bhead) slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
+        // every lane takes the slot of the nearest block head at or below it, or the carry of the previous round
+        const u64 bheads = __ballot(bhead);
+        const u64 upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        const u64 b_below = bheads & upto;
+        const int src = b_below ? (63 - __clzll(static_cast<long long>(b_below))) : 0;
+        const u32 head_slot = static_cast<u32>(__shfl(static_cast<int>(slot), src, 64));
+        const u32 my_slot = b_below ? head_slot : carry_slot;
+        const u32 prev_z = static_cast<u32>(__shfl_up(static_cast<int>(zs), 1, 64));
+        const bool thead = act && (lane == 0 || bhead || zs != prev_z);
+        const u64 theads = __ballot(thead);
+        // the step's byte, at its offset inside its piece (lane 0 is a head: every lane has one at or below it)
+        if constexpr (kAxisCap * 3 * sizeof(float) >= 64 * 32) {
+          // staged in LDS (the crossing times are not needed any more) and written out as whole 32-B slots: the pieces of a
+          // round are consecutive slots, so the wave streams np x 32 contiguous bytes instead of 64 scattered bytes
+          uint8_t* stage = reinterpret_cast<uint8_t*>(tl);
+          if (act) {
+            const u64 t_below = theads & upto;
+            const u32 kl = static_cast<u32>(__popcll(t_below)) - 1u;
+            const u32 hl = 63u - static_cast<u32>(__clzll(static_cast<long long>(t_below)));
+            stage[kl * 32u + (lane - hl)] = static_cast<uint8_t>(lin);
+          }
+          wave_lds_handover();
+          const u32 ndw = static_cast<u32>(__popcll(theads)) * 8u;
+          const u32* stage32 = reinterpret_cast<const u32*>(tl);
+          u32* out32 = reinterpret_cast<u32*>(lin8);
+          if (!overflow)
+            for (u32 i = lane; i < ndw; i += 64)
+              if (pk + (i >> 3) < bound) out32[static_cast<size_t>(poff + pk) * 8u + i] = stage32[i];
+          wave_lds_handover();
+        } else if (act && !overflow) {
+          const u64 t_below = theads & upto;
+          const u32 k = pk + static_cast<u32>(__popcll(t_below)) - 1u;
+          const u32 hl = 63u - static_cast<u32>(__clzll(static_cast<long long>(t_below)));
+          if (k < bound) lin8[static_cast<size_t>(poff + k) * 32u + (lane - hl)] = static_cast<uint8_t>(lin);
+        }
+        if (thead && !overflow) {
+          const u32 k = pk + static_cast<u32>(__popcll(theads & ((1ull << lane) - 1ull)));
+          const u64 above = (lane == 63) ? 0ull : (theads >> (lane + 1));
+          const u32 round_end = min(64u, ns - base);
+          const u32 nxt = above ? (lane + static_cast<u32>(__ffsll(static_cast<long long>(above)))) : round_end;
+          if (k < bound) {
+            PA.key[poff + k] = (my_slot == kInvalid) ? kInvalid : ((my_slot << 4) | zs);
+            PA.start[poff + k] = poff + k;
+            PA.raylen[poff + k] = (r << kPieceLenBits) | (nxt - lane);
+          } else {
+            atomicOr(&cnt->err, kErrRecords);
+          }
+        }
+        pk += static_cast<u32>(__popcll(theads));
+        carry_key = __shfl(bkey, 63, 64);
+        carry_slot = static_cast<u32>(__shfl(static_cast<int>(my_slot), 63, 64));
+      }
+      wave_lds_handover();  // the next ray of this wave reuses the LDS scratch
+    } else {
+      // sequential fallback (lane 0)
+      if (lane == 0) {
+        u64 last_bkey = kEmptyKey;
+        u32 last_slot = kInvalid, last_z = 0, run = 0;
+        for (u32 s = 0; s < ns; ++s) {
+          const int x = d.c[0], y = d.c[1], z = d.c[2];
+          dda_step(d);
+          const u64 bkey = pack_key(x >> 4, y >> 4, z >> 4);
+          const u32 zs = static_cast<u32>(z & 15);
+          bool head = (s == 0) || zs != last_z || run == 31u;
+          if (bkey != last_bkey) {
+            last_bkey = bkey;
+            last_slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
+            head = true;
+          }
+          last_z = zs;
+          if (overflow) continue;
+          if (head) {
+            if (pk < bound) {
+              PA.key[poff + pk] = (last_slot == kInvalid) ? kInvalid : ((last_slot << 4) | zs);
+              PA.start[poff + pk] = poff + pk;
+              PA.raylen[poff + pk] = (r << kPieceLenBits) | 1u;
+            } else {
+              atomicOr(&cnt->err, kErrRecords);
+            }
+            pk += 1;
+            run = 0;
+          } else if (pk <= bound) {
+            PA.raylen[poff + pk - 1] += 1u;
+          }
+          if (pk <= bound) lin8[static_cast<size_t>(poff + pk - 1) * 32u + run] = static_cast<uint8_t>((x & 15) | ((y & 15) << 4));
+          run += 1;
+        }
+      }
+      pk = static_cast<u32>(__shfl(static_cast<int>(pk), 0, 64));
+    }
+    // the slots of the bound this ray did not use
+    if (!overflow)
+      for (u32 i = pk + lane; i < bound; i += 64) PA.key[poff + i] = kInvalid;
+  }
+}
+
+// block ordinals of the frame -> piece keys = ordinal << 4 | z slab (the tile id); also what k_emit* publish for the record
+// path: the ordinal table and the key width of the sort
+__global__ void __launch_bounds__(256) k_piece_keys(LayerView L, u32* __restrict__ pkey, u32 rec_cap, u32 piece_cap, Counters* cnt, SortInfo* sort_info,
+                                                    const u32* __restrict__ touched_slots, int4* __restrict__ ord_info) {
+  fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
+  const u32 n = cnt->n_piece_slots;
+  const bool overflow = cnt->n_records > rec_cap || n > piece_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    u32 bits = 4;  // ordinals are < n_touched; the invalid key's bits (all ones) must sort after every valid tile id
+    while ((1ull << (bits - 4)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
+    sort_info->nbits = overflow ? 0u : bits;  // 0 bits: every sort pass exits at once
+    sort_info->parity = 0;
+    sort_info->base = 0;
+    if (overflow) atomicOr(&cnt->err, kErrRecords);
+  }
+  if (overflow) return;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 k = pkey[i];
+    if (k == kInvalid) continue;
+    const u32 slot = k >> 4;
+    if (L.ht_vals[slot] == kInvalid) {
+      atomicOr(&cnt->err, kErrPool);  // block without storage: these updates are lost
+      pkey[i] = kInvalid;
+    } else {
+      pkey[i] = (L.ht_ord[slot] << 4) | (k & 15u);
     }
   }
 }
@@ -1237,18 +1516,85 @@ constexpr u32 kTileShift = 12 - kSlabBits;                 // tile id = voxel id
 constexpr u32 kTileVox = 1u << kTileShift;                 // 256 voxels per tile
 constexpr u32 kTilesPerBlock = 1u << kSlabBits;
 constexpr u32 kHardBatch = 1024;
-constexpr u32 kBT = 256, kBW = kBT / 64;
+constexpr u32 kBT = 512, kBW = kBT / 64;  // two waves per SIMD: a tile is a chain of dependent global round trips
 
-__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, const Counters* cnt) {
+// tile id = key >> shift (records: kTileShift; pieces: 0, the key is the tile id)
+__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, const Counters* cnt, u32 shift) {
   const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
   const u32* __restrict__ key = V.key[V.info->parity & 1u];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u32 k = key[i];
     if (k == kInvalid) continue;
-    const u32 t = k >> kTileShift;
-    if (i == 0 || (key[i - 1] >> kTileShift) != t) tile_beg[t] = i;
-    if (i + 1 == n || (key[i + 1] >> kTileShift) != t) tile_end[t] = i + 1;
+    const u32 t = k >> shift;
+    if (i == 0 || (key[i - 1] >> shift) != t) tile_beg[t] = i;
+    if (i + 1 == n || (key[i + 1] >> shift) != t) tile_end[t] = i + 1;
   }
+}
+
+// Flush of a batch of `fill` hard records (block-wide; every thread calls it): sort the batch by voxel in LDS (stable
+// counting sort: per-voxel counts, exclusive scan, wave match-any ranks, waves in turn), then every voxel replays its run
+// in order with the reference's updateTsdfVoxel.  acc_cnt / acc_sum are scratch here (phases 1-2 are over).
+template <u32 kT>
+__device__ __forceinline__ void tile_flush(const FrameParams& P, u32* blk, u32* acc_cnt, u32* acc_sum, const unsigned short* b_lin, const float* b_sdf,
+                                           const float* b_uw, const u32* b_col, unsigned short* perm, u32* scan_lds, u32 fill, u32 tid, u32 lane, u32 wave) {
+  if (tid < kTileVox) acc_cnt[tid] = 0;
+  __syncthreads();
+  for (u32 p = tid; p < fill; p += kT) atomicAdd(&acc_cnt[b_lin[p] & (kTileVox - 1u)], 1u);
+  __syncthreads();
+  {  // exclusive scan over the tile's voxels (thread = voxel)
+    const u32 c = (tid < kTileVox) ? acc_cnt[tid] : 0u;
+    u32 tot;
+    const u32 ex = block_exclusive_scan<kT / 64>(c, &tot, scan_lds);
+    if (tid < kTileVox) acc_sum[tid] = ex;
+  }
+  __syncthreads();
+  const u32 chunk = ((fill + kT - 1u) / kT) * 64u;  // positions per wave, a multiple of 64
+  for (u32 w = 0; w < kT / 64; ++w) {
+    if (wave == w) {
+      const u32 wbeg = min(fill, w * chunk), wend = min(fill, wbeg + chunk);
+      for (u32 p0 = wbeg; p0 < wend; p0 += 64) {
+        const u32 p = p0 + lane;
+        const bool valid = p < wend;
+        const u32 lin = valid ? (b_lin[p] & (kTileVox - 1u)) : 0u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (u32 b = 0; b < kTileShift; ++b) {
+          const bool bit = (lin >> b) & 1u;
+          const u64 m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+        const u64 lower = peers & ((1ull << lane) - 1ull);
+        if (valid) perm[acc_sum[lin] + static_cast<u32>(__popcll(lower))] = static_cast<unsigned short>(p);
+        wave_lds_handover();
+        if (valid && lower == 0ull) acc_sum[lin] += static_cast<u32>(__popcll(peers));
+        wave_lds_handover();
+      }
+    }
+    __syncthreads();
+  }
+  {
+    const u32 v = tid & (kTileVox - 1u);
+    const u32 c = (tid < kTileVox) ? acc_cnt[v] : 0u;
+    if (c) {
+      const u32 e = acc_sum[v];
+      Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
+      for (u32 j = e - c; j < e; ++j) {
+        const u32 idx = perm[j];
+        const float uw = b_uw[idx];
+        // a saturating record on a voxel that sits at +truncation only adds its weight: exactly what updateTsdfVoxel
+        // computes there (distance provably stays == truncation -- saturating_update -- and the weight is the same
+        // float addition), without its divisions: most records of a dirty voxel's run
+        if ((b_lin[idx] & 0x8000u) && vx.d == P.trunc)
+          vx.w = std_min(P.max_weight, vx.w + uw);
+        else
+          update_voxel(P, vx, b_sdf[idx], uw, b_col[idx]);
+      }
+      blk[3 * v] = __float_as_uint(vx.d);
+      blk[3 * v + 1] = __float_as_uint(vx.w);
+      blk[3 * v + 2] = vx.c;
+    }
+  }
+  __syncthreads();
 }
 
 __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
@@ -1319,8 +1665,8 @@ __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restri
     __syncthreads();
     // ---- 2. fold what folds (thread = voxel) ----------------------------------------------------------------------------
     {
-      const u32 v = tid;
-      const u32 c = acc_cnt[v], count = c & 0x7FFFFFFFu;
+      const u32 v = tid & (kTileVox - 1u);
+      const u32 c = (tid < kTileVox) ? acc_cnt[v] : 0u, count = c & 0x7FFFFFFFu;
       bool hard = false;
       if (count) {
         my_updates += count;
@@ -1344,7 +1690,7 @@ __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restri
         }
       }
       const u64 hm = __ballot(hard);
-      if (lane == 0) {
+      if (lane == 0 && tid < kTileVox) {
         hardbits[wave * 2] = static_cast<u32>(hm);
         hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
         if (hm) any_hard_s = 1;
@@ -1359,63 +1705,7 @@ __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restri
         if (done || fill + kBT > kHardBatch) {
           // -- flush: sort the batch by voxel (stable), replay every voxel's run in order
           if (fill) {
-            acc_cnt[tid] = 0;
-            __syncthreads();
-            for (u32 p = tid; p < fill; p += kBT) atomicAdd(&acc_cnt[b_lin[p] & (kTileVox - 1u)], 1u);
-            __syncthreads();
-            {  // exclusive scan over the tile's voxels (thread = voxel)
-              const u32 c = acc_cnt[tid];
-              u32 tot;
-              acc_sum[tid] = block_exclusive_scan<kBW>(c, &tot, scan_lds);
-            }
-            __syncthreads();
-            const u32 chunk = ((fill + kBT - 1u) / kBT) * 64u;  // positions per wave, a multiple of 64
-            for (u32 w = 0; w < kBW; ++w) {
-              if (wave == w) {
-                const u32 wbeg = min(fill, w * chunk), wend = min(fill, wbeg + chunk);
-                for (u32 p0 = wbeg; p0 < wend; p0 += 64) {
-                  const u32 p = p0 + lane;
-                  const bool valid = p < wend;
-                  const u32 lin = valid ? (b_lin[p] & (kTileVox - 1u)) : 0u;
-                  u64 peers = __ballot(valid);
-#pragma unroll
-                  for (u32 b = 0; b < kTileShift; ++b) {
-                    const bool bit = (lin >> b) & 1u;
-                    const u64 m = __ballot(bit);
-                    peers &= bit ? m : ~m;
-                  }
-                  const u64 lower = peers & ((1ull << lane) - 1ull);
-                  if (valid) perm[acc_sum[lin] + static_cast<u32>(__popcll(lower))] = static_cast<unsigned short>(p);
-                  wave_lds_handover();
-                  if (valid && lower == 0ull) acc_sum[lin] += static_cast<u32>(__popcll(peers));
-                  wave_lds_handover();
-                }
-              }
-              __syncthreads();
-            }
-            {
-              const u32 v = tid;
-              const u32 c = acc_cnt[v];
-              if (c) {
-                const u32 e = acc_sum[v];
-                Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
-                for (u32 j = e - c; j < e; ++j) {
-                  const u32 idx = perm[j];
-                  const float uw = b_uw[idx];
-                  // a saturating record on a voxel that sits at +truncation only adds its weight: exactly what updateTsdfVoxel
-                  // computes there (distance provably stays == truncation -- saturating_update -- and the weight is the same
-                  // float addition), without its divisions: most records of a dirty voxel's run
-                  if ((b_lin[idx] & 0x8000u) && vx.d == P.trunc)
-                    vx.w = std_min(P.max_weight, vx.w + uw);
-                  else
-                    update_voxel(P, vx, b_sdf[idx], uw, b_col[idx]);
-                }
-                blk[3 * v] = __float_as_uint(vx.d);
-                blk[3 * v + 1] = __float_as_uint(vx.w);
-                blk[3 * v + 2] = vx.c;
-              }
-            }
-            __syncthreads();
+            tile_flush<kBT>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
             fill = 0;
           }
           if (done) break;
@@ -1461,6 +1751,256 @@ __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restri
   }
   if (lane == 0 && my_voxels) {
     u32* sh = cnt->shard[(blockIdx.x * kBW + wave) & 63u];
+    atomicAdd(&sh[kShUpdates], my_updates);
+    atomicAdd(&sh[kShVoxels], my_voxels);
+    atomicMax(&sh[kShMaxRun], my_maxrun);
+  }
+}
+
+// ---- piece apply: k_apply_block's four phases, the tile's steps gathered through its pieces ------------------------------------
+// The pieces arrive sorted by tile, ray order inside a tile preserved (stable sort of slots that were laid out in ray order).
+// A round takes up to 256 pieces, thread = piece: header (slot, ray, length), the piece's bytes with one or two 16-B loads,
+// the ray once per piece -- a step costs one byte of HBM traffic instead of an 8-B record.  The round is then EXPANDED in LDS
+// into its steps (exclusive scan of the lengths; step -> voxel byte, piece), in (piece, step) = ray order, and phases 1 and
+// 3 run over the steps with one lane per step exactly like k_apply_block runs over records.  A tile of at most 256 pieces
+// (nearly all of them at fine voxels) is expanded once; the next tile's range is fetched while this one is worked on.
+constexpr u32 kPT = 256, kPW = kPT / 64;
+constexpr u32 kPieceBatch = 768;
+constexpr u32 kStepCap = kPT * 31;  // steps of one round
+struct PieceView {
+  const u32* key[2];
+  const u32* start[2];
+  const u32* raylen[2];
+  const SortInfo* info;
+};
+typedef u32 U32x4 __attribute__((ext_vector_type(4)));
+
+// compute_sdf with the ray's part (dv = point_G - origin, dist = |dv|) taken from RayArrays::q: the same operations on the same values
+__device__ __forceinline__ float step_sdf(const FrameParams& P, F3 dv, float dist, int gx, int gy, int gz) {
+  const F3 origin{P.tx, P.ty, P.tz};
+  const F3 c{center_coord(gx, P.voxel_size), center_coord(gy, P.voxel_size), center_coord(gz, P.voxel_size)};
+  const F3 v = c - origin;
+  const float proj = dot3(v, dv) / dist;
+  return dist - proj;
+}
+
+// f(j, lin) for every step j < len of this lane's piece, lanes in lockstep (j is wave-uniform; every lane of the wave must call)
+template <typename F>
+__device__ __forceinline__ void piece_for_each(u32 len, const u64 (&H)[4], F&& f) {
+#pragma unroll
+  for (u32 h = 0; h < 4; ++h) {
+    if (__ballot(8u * h < len) == 0ull) break;
+    u64 cur = H[h];
+#pragma unroll 1
+    for (u32 b = 0; b < 8; ++b) {
+      const u32 j = 8u * h + b;
+      const bool on = j < len;
+      if (__ballot(on) == 0ull) break;
+      const u32 lin = static_cast<u32>(cur) & 255u;
+      cur >>= 8;
+      if (on) f(j, lin);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kPT) k_apply_pieces(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, PieceView V,
+                                                      const uint8_t* __restrict__ lin8, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt,
+                                                      u32* layer_err, u32* __restrict__ h_nblocks) {
+  const FrameParams P = *Pp;
+  __shared__ u32 blk[kTileVox * kWordsPerVoxel];
+  __shared__ u32 acc_sum[kTileVox];
+  __shared__ u32 acc_cnt[kTileVox];
+  __shared__ u32 hardbits[kTileVox / 32];
+  __shared__ uint8_t s_lin[kStepCap], s_pc[kStepCap];             // the round's steps: voxel byte, piece (= thread that loaded it)
+  __shared__ float pr_x[kPT], pr_y[kPT], pr_z[kPT], pr_d[kPT], pr_w[kPT];  // the round's pieces: point_G - origin, its length, the ray's weight
+  __shared__ u32 pr_ray[kPT];
+  __shared__ float b_sdf[kPieceBatch], b_uw[kPieceBatch];
+  __shared__ u32 b_col[kPieceBatch];
+  __shared__ unsigned short b_lin[kPieceBatch], perm[kPieceBatch];
+  __shared__ u32 wsum[kPW], scan_lds[kPW], any_hard_s;
+  static_assert(kPT == kTileVox, "phase 2 and the flush use thread = voxel");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // last kernel of the frame (see k_apply_block)
+    if (cnt->err) atomicOr(layer_err, cnt->err);
+    *h_nblocks = min(*L.d_nblocks, L.capacity);
+  }
+  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTilesPerBlock;
+  const u32 par = V.info->parity & 1u;
+  const u32* __restrict__ p_start = V.start[par];
+  const u32* __restrict__ p_raylen = V.raylen[par];
+  const U32x4* __restrict__ lin128 = reinterpret_cast<const U32x4*>(lin8);
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool exact_cap = P.max_weight <= 16711680.0f;
+  u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
+  u32 tile = blockIdx.x;
+  u32 nbeg = 0, nend = 0;
+  int4 ninfo = make_int4(0, 0, 0, 0);
+  if (tile < n_tiles) {
+    nbeg = tile_beg[tile];
+    nend = tile_end[tile];
+    ninfo = ord_info[tile >> kSlabBits];
+  }
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const u32 beg = nbeg, end = nend;
+    const int4 info = ninfo;
+    if (tile + gridDim.x < n_tiles) {  // the next tile's range: in flight while this tile is worked on
+      nbeg = tile_beg[tile + gridDim.x];
+      nend = tile_end[tile + gridDim.x];
+      ninfo = ord_info[(tile + gridDim.x) >> kSlabBits];
+    }
+    if (end <= beg) continue;  // (uniform) no piece in this slab of the block
+    __syncthreads();           // everybody has read the range and is done with the previous tile's LDS
+    if (tid == 0) {
+      tile_beg[tile] = 0;  // leave the tables empty for the next frame
+      tile_end[tile] = 0;
+      any_hard_s = 0;
+    }
+    const u32 pool = static_cast<u32>(info.w);
+    if (pool == kInvalid) continue;  // (uniform; such a block's pieces carry invalid keys anyway)
+    const int gz = info.z + static_cast<int>(tile & (kTilesPerBlock - 1u));
+    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTilesPerBlock - 1u)) * kTileVox) * kWordsPerVoxel;
+    // expand the round of pieces [pb, pb + kPT) into s_lin / s_pc / pr_*; returns its number of steps (block-wide)
+    auto expand_round = [&](u32 pb) -> u32 {
+      const u32 pi = pb + tid;
+      u32 len = 0;
+      u64 H[4] = {0, 0, 0, 0};
+      if (pi < end) {
+        const u32 st = p_start[pi], rl = p_raylen[pi];
+        const u32 r = rl >> kPieceLenBits;
+        len = rl & ((1u << kPieceLenBits) - 1u);
+        const U32x4 a = lin128[static_cast<size_t>(st) * 2u];
+        U32x4 b = {0, 0, 0, 0};
+        if (len > 16u) b = lin128[static_cast<size_t>(st) * 2u + 1u];
+        typedef float F4 __attribute__((ext_vector_type(4)));
+        const F4* q = reinterpret_cast<const F4*>(R.q + static_cast<size_t>(r) * 8u);
+        const F4 q0 = q[0];
+        pr_w[tid] = q[1].x;
+        pr_x[tid] = q0.x;
+        pr_y[tid] = q0.y;
+        pr_z[tid] = q0.z;
+        pr_d[tid] = q0.w;
+        pr_ray[tid] = r;
+        H[0] = a.x | (static_cast<u64>(a.y) << 32);
+        H[1] = a.z | (static_cast<u64>(a.w) << 32);
+        H[2] = b.x | (static_cast<u64>(b.y) << 32);
+        H[3] = b.z | (static_cast<u64>(b.w) << 32);
+      }
+      u32 tot;
+      const u32 off = block_exclusive_scan<kPW>(len, &tot, scan_lds);
+      piece_for_each(len, H, [&](u32 j, u32 lin) {
+        s_lin[off + j] = static_cast<uint8_t>(lin);
+        s_pc[off + j] = static_cast<uint8_t>(tid);
+      });
+      __syncthreads();
+      return tot;
+    };
+    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kPT) blk[i] = gblk[i];
+    acc_sum[tid] = 0;
+    acc_cnt[tid] = 0;
+    const bool keeps = end - beg <= kPT;  // one round: its expansion serves phase 3 too
+    u32 T = 0;
+    // ---- 1. classify (lane = step) ------------------------------------------------------------------------------------
+    for (u32 pb = beg; pb < end; pb += kPT) {
+      if (pb != beg) __syncthreads();  // the previous round's steps have been consumed
+      T = expand_round(pb);            // (its barrier also covers blk / acc_*)
+      for (u32 s0 = tid; s0 < T; s0 += kPT) {
+        const u32 lin = s_lin[s0], pc = s_pc[s0];
+        const float sdf = step_sdf(P, F3{pr_x[pc], pr_y[pc], pr_z[pc]}, pr_d[pc], info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+        const float uw = update_weight(P, sdf, pr_w[pc]);
+        bool fold = foldable_update(P, sdf, uw);
+        if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
+        atomicAdd(&acc_cnt[lin], 1u);
+        if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
+      }
+    }
+    __syncthreads();
+    // ---- 2. fold what folds (thread = voxel) ----------------------------------------------------------------------------
+    {
+      const u32 v = tid;
+      const u32 c = acc_cnt[v], count = c & 0x7FFFFFFFu;
+      bool hard = false;
+      if (count) {
+        my_updates += count;
+        my_voxels += 1;
+        my_maxrun = max(my_maxrun, count);
+        const float d = __uint_as_float(blk[3 * v]), w = __uint_as_float(blk[3 * v + 1]);
+        const u32 sum = acc_sum[v];
+        hard = true;
+        if (!(c >> 31) && sum < (1u << 30) && (w == 0.0f || d == P.trunc)) {
+          if (w >= P.max_weight) {
+            hard = false;  // min(max_weight, w + u) == max_weight for every u > 0: nothing changes
+          } else if (w == truncf(w) && w >= 0.0f) {
+            const unsigned long long total = static_cast<unsigned long long>(w) + sum;
+            if (total < 16777216ull || exact_cap) {
+              const float ft = static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u);
+              blk[3 * v] = __float_as_uint(P.trunc);
+              blk[3 * v + 1] = __float_as_uint(ft >= P.max_weight ? P.max_weight : ft);
+              hard = false;
+            }
+          }
+        }
+      }
+      const u64 hm = __ballot(hard);
+      if (lane == 0) {
+        hardbits[wave * 2] = static_cast<u32>(hm);
+        hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
+        if (hm) any_hard_s = 1;
+      }
+    }
+    __syncthreads();
+    // ---- 3. the hard voxels: ordered replay (lane = step, chunks of kPT steps in ray order) ---------------------------
+    if (any_hard_s) {
+      u32 fill = 0;
+      for (u32 pb = beg; pb < end; pb += kPT) {
+        if (!keeps) {
+          __syncthreads();
+          T = expand_round(pb);
+        }
+        for (u32 base = 0; base < T; base += kPT) {
+          if (fill + kPT > kPieceBatch) {
+            tile_flush<kPT>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
+            fill = 0;
+          }
+          const u32 s0 = base + tid;
+          bool keep = false;
+          u32 lin = 0;
+          if (s0 < T) {
+            lin = s_lin[s0];
+            keep = (hardbits[lin >> 5] >> (lin & 31u)) & 1u;
+          }
+          const u64 m = __ballot(keep);
+          if (lane == 0) wsum[wave] = static_cast<u32>(__popcll(m));
+          __syncthreads();
+          u32 pos = fill + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
+          for (u32 w = 0; w < wave; ++w) pos += wsum[w];
+          if (keep) {
+            const u32 pc = s_pc[s0];
+            const float sdf = step_sdf(P, F3{pr_x[pc], pr_y[pc], pr_z[pc]}, pr_d[pc], info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+            const float uw = update_weight(P, sdf, pr_w[pc]);
+            b_lin[pos] = static_cast<unsigned short>(lin | (foldable_update(P, sdf, uw) ? 0x8000u : 0u));
+            b_sdf[pos] = sdf;
+            b_uw[pos] = uw;
+            b_col[pos] = R.color[pr_ray[pc]];
+          }
+#pragma unroll
+          for (u32 w = 0; w < kPW; ++w) fill += wsum[w];
+          __syncthreads();
+        }
+      }
+      if (fill) tile_flush<kPT>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
+    }
+    // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
+    __syncthreads();
+    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kPT) gblk[i] = blk[i];
+  }
+  // statistics
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    my_updates += __shfl_xor(my_updates, off, 64);
+    my_voxels += __shfl_xor(my_voxels, off, 64);
+    my_maxrun = max(my_maxrun, static_cast<u32>(__shfl_xor(static_cast<int>(my_maxrun), off, 64)));
+  }
+  if (lane == 0 && my_voxels) {
+    u32* sh = cnt->shard[(blockIdx.x * kPW + wave) & 63u];
     atomicAdd(&sh[kShUpdates], my_updates);
     atomicAdd(&sh[kShVoxels], my_voxels);
     atomicMax(&sh[kShMaxRun], my_maxrun);
@@ -1563,6 +2103,9 @@ struct BundleSet {  // lives A1 .. A2
 struct RecordSet {  // lives B1 .. B2
   u32 *rec_key[2] = {nullptr, nullptr}, *rec_ray[2] = {nullptr, nullptr};
   u32 *piece_front = nullptr, *piece_back = nullptr, *piece_wsum = nullptr;
+  // piece path (merged): the walk as bytes + the (ray, tile) pieces, ping-pong for their sort; the record arrays stay unallocated
+  uint8_t* lin8 = nullptr;
+  u32 *pkey[2] = {nullptr, nullptr}, *pstart[2] = {nullptr, nullptr}, *prl[2] = {nullptr, nullptr};
   u32* touched_slots = nullptr;  // [layer ht_cap]
   int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
   u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap * 16] record range of every tile (block apply); zero between frames
@@ -1588,7 +2131,69 @@ struct FastState {
   uint64_t sweeps_total = 0, frames = 0;
 };
 
+// ---- submission thread ------------------------------------------------------------------------------------------------
+// At 5 cm a frame is ~30 launches and the stream is bound by the host's launch rate, not by the GPU.  The caller's thread
+// enqueues stages A1 / A2 and returns; this thread enqueues B1 / B2 of the same frame behind it (at most one frame behind:
+// the per-slot events it records are waited for by the caller's thread two and four frames later).
+struct Submitter {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  std::deque<std::function<int()>> q;
+  uint64_t posted = 0, finished = 0;
+  int status = COX_OK;  // first error of a job; reported (and cleared) by the next drain
+  bool stop = false;
+  int device = 0;
+  void run() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::function<int()> job;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_job.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        job = std::move(q.front());
+        q.pop_front();
+      }
+      const int st = job();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (st != COX_OK && status == COX_OK) status = st;
+        finished += 1;
+      }
+      cv_done.notify_all();
+    }
+  }
+  void post(std::function<int()> job) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      q.push_back(std::move(job));
+      posted += 1;
+    }
+    cv_job.notify_one();
+  }
+  // returns when at most `outstanding` posted jobs have not been enqueued completely
+  void wait_outstanding(uint64_t outstanding) {
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return posted - finished <= outstanding; });
+  }
+  int take_status() {
+    std::lock_guard<std::mutex> lk(m);
+    const int st = status;
+    status = COX_OK;
+    return st;
+  }
+};
+static std::mutex g_submitters_mutex;
+static std::vector<Submitter*> g_submitters;
+void cox_drain_submitters() {
+  std::lock_guard<std::mutex> lk(g_submitters_mutex);
+  for (Submitter* s : g_submitters) s->wait_outstanding(0);
+}
+
 struct cox_integrator {
+  Submitter* submitter = nullptr;  // simple / merged; COX_SUBMIT_THREAD=0 turns it off
+  uint64_t host_ns = 0, host_wait_ns = 0, host_frames = 0;  // time the caller's thread spends inside the integrate call (enqueueing, waiting for a free slot)
   cox_projective* proj = nullptr;  // method == COX_METHOD_PROJECTIVE: everything else below stays empty
   cox_layer* layer = nullptr;
   FastState fast;
@@ -1605,6 +2210,11 @@ struct cox_integrator {
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
   bool small_axis_cap = false;  // no ray can cross more than kAxisCapSmall - 2 planes of one axis
   u32 layer_generation = 0;     // cox_layer::generation the layer-sized buffers (touched_slots, ord_info, graphs) belong to
+  hipEvent_t timeline_ref = nullptr;
+  FILE* timeline = nullptr;
+  u32 grid_apply = 8192, grid_merge = 4096, grid_touch = 2048;  // grid-stride kernels: any size is correct (COX_GRID_* for experiments)
+  bool piece_path = false;      // COX_APPLY=pieces (merged without anti-grazing): pieces instead of records (k_touch_pieces / k_apply_pieces)
+  u32 piece_cap = 0;
   bool block_apply = true;      // records partitioned by block + k_apply_block; COX_APPLY=records selects the per-record kernels (full sort)
   // ordering against the caller's stream (cox_integrator_set_input_stream): the first stage waits for what the producer has
   // enqueued, and the producer's stream waits until the engine has read the inputs (stream-ordered allocators may then
@@ -1631,7 +2241,7 @@ struct cox_integrator {
   u32 profile_every = 1;  // time the kernels of every n-th frame
   // one (begin, end) event pair per timed region of a frame, by kernel class (cox_kernel_class in coxgraph_hip.h)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[COX_KERNEL_CLASSES];
-  std::vector<hipEvent_t> event_pool;
+  std::vector<hipEvent_t> event_pool[2];  // [1]: the submission thread's
   double class_ms[COX_KERNEL_CLASSES] = {};
   uint64_t class_regions[COX_KERNEL_CLASSES] = {};
 };
@@ -1673,6 +2283,11 @@ static u32 max_steps_per_ray(const cox_integrator* I) {
 }
 
 static int sync_all(cox_integrator* I) {
+  if (I->submitter) {
+    I->submitter->wait_outstanding(0);
+    const int st = I->submitter->take_status();
+    if (st != COX_OK) return st;
+  }
   for (int k = 0; k < 4; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
   return COX_OK;
@@ -1703,6 +2318,9 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&R.key, cap));
     COX_TRY(dev_realloc(&R.nsteps, cap));
     COX_TRY(dev_realloc(&R.rec_off, cap));
+    COX_TRY(dev_realloc(&R.pbound, cap));
+    COX_TRY(dev_realloc(&R.q, static_cast<size_t>(cap) * 8));
+    COX_TRY(dev_realloc(&R.piece_off, cap));
     COX_TRY(dev_realloc(&F.fh_keys, static_cast<size_t>(I->fh_cap) + I->fh_cap / 2 + 1));  // u64 keys + u32 first-seq behind them
     F.fh_first = reinterpret_cast<u32*>(F.fh_keys + I->fh_cap);
     COX_HIP(hipMemset(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap));  // empty; every frame leaves it empty again
@@ -1732,7 +2350,21 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   const u64 limit = 0x7FFFFFF0ull;
   const u32 rcap = static_cast<u32>(std::min(want, limit));
   const u32 wave_cap = rcap / 64 + 2;
+  // pieces: every ray at the bound of the longest wave-walked ray (piece_bound); a frame of sequentially walked rays may need
+  // more (one piece per step at worst) -- that frame is dropped and reported like a record overflow
+  const u32 planes = (I->steps_max - 1) / 3;
+  const u64 per_ray = static_cast<u64>(I->steps_max + 63) / 64 + (planes + 2) + 2 * ((planes + 2) / 16 + 1) + 4;
+  const u32 piece_cap = static_cast<u32>(std::min<u64>(rcap, static_cast<u64>(cap) * per_ray));
   for (RecordSet& S : I->rs) {
+    if (I->piece_path) {
+      COX_TRY(dev_realloc(&S.lin8, static_cast<size_t>(piece_cap) * 32));
+      for (int k = 0; k < 2; ++k) {
+        COX_TRY(dev_realloc(&S.pkey[k], piece_cap));
+        COX_TRY(dev_realloc(&S.pstart[k], piece_cap));
+        COX_TRY(dev_realloc(&S.prl[k], piece_cap));
+      }
+      continue;
+    }
     for (int k = 0; k < 2; ++k) {
       COX_TRY(dev_realloc(&S.rec_key[k], rcap));
       COX_TRY(dev_realloc(&S.rec_ray[k], rcap));
@@ -1741,7 +2373,8 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&S.piece_back, wave_cap));
     COX_TRY(dev_realloc(&S.piece_wsum, static_cast<size_t>(wave_cap) * 2));
   }
-  COX_TRY(alloc_sort_ws(&I->sort_rec, rcap));
+  I->piece_cap = piece_cap;
+  COX_TRY(alloc_sort_ws(&I->sort_rec, I->piece_path ? piece_cap : rcap));
   if (I->method == COX_METHOD_FAST) {
     COX_TRY(alloc_sort_ws(&I->sort_vis, rcap));
     FastState& X = I->fast;
@@ -1813,18 +2446,25 @@ static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n,
 static inline dim3 grid_for(u32 n, u32 block = 256, u32 cap = 0x7FFFFFFFu) { return dim3(std::min<u32>(cap, std::max<u32>(1, (n + block - 1) / block))); }
 
 // HIP-event timing of one kernel class inside a frame (bench.py roofline): begin / end on the stream the kernels run on
+// classes whose regions are opened by the submission thread (stages B1 / B2; not for fast, which has none) take their
+// events from a pool of their own
+static inline int event_pool_of(const cox_integrator* I, int cls) {
+  return (I->submitter && (cls == COX_KC_APPLY || cls == COX_KC_TOUCH_EMIT || cls == COX_KC_RECORD_SORT)) ? 1 : 0;
+}
+static thread_local u64 tl_frame_no = 0;  // the frame whose stages this thread is enqueueing (StageCtx::frame)
 struct TimedRegion {
   cox_integrator* I;
   int cls;
   hipStream_t s;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   TimedRegion(cox_integrator* I_, int cls_, hipStream_t s_) : I(I_), cls(cls_), s(s_) {
-    if (!(I->profiling && (I->frame_no % I->profile_every == 0))) return;
+    if (!(I->profiling && (tl_frame_no % I->profile_every == 0))) return;
+    std::vector<hipEvent_t>& pool = I->event_pool[event_pool_of(I, cls)];
     // events come from a pool that the drain refills: creating them costs more than recording them
     auto take = [&]() -> hipEvent_t {
-      if (!I->event_pool.empty()) {
-        hipEvent_t e = I->event_pool.back();
-        I->event_pool.pop_back();
+      if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
         return e;
       }
       hipEvent_t e = nullptr;
@@ -1852,7 +2492,9 @@ struct StageCtx {
   BundleSet* B;
   RecordSet* S;
   int slot;
+  u64 frame;  // frame number (which frames carry timing events)
 };
+
 static LayerView layer_view(const cox_layer* Lh) {
   return LayerView{Lh->voxels, Lh->ht_keys, Lh->ht_vals, Lh->ht_stamp, Lh->ht_ord, Lh->block_keys, Lh->d_nblocks, Lh->ht_cap - 1, static_cast<u32>(Lh->capacity)};
 }
@@ -1891,12 +2533,13 @@ static int stage_a2(const StageCtx& c, hipStream_t s) {
   const u32 n = I->pcap;
   if (I->method == COX_METHOD_MERGED) {
     BundleView V{{B.skey[0], B.skey[1]}, {B.sval[0], B.sval[1]}, B.sort_info};
-    hipLaunchKernelGGL(k_bundle_heads, grid_for(n), dim3(256), 0, s, F.d_params, V, B.head);
-    // bundle ordinal of every head = exclusive scan of the head flags; total = number of bundles (rays)
-    exclusive_scan_u32(B.head, B.head, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
-    hipLaunchKernelGGL(k_bundle_starts, grid_for(n), dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
+    // bundle boundaries: heads per tile (+ their scan by the last workgroup), then the starts
+    const dim3 gt(std::max<u32>(1, (n + kBoundTile - 1) / kBoundTile));
+    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head, F.cnt);
+    hipLaunchKernelGGL(k_bundle_starts, gt, dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
     TimedRegion t(I, COX_KC_MERGE, s);
-    hipLaunchKernelGGL(k_bundle_merge, dim3(4096), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt);
+    hipLaunchKernelGGL(k_bundle_merge, dim3(I->grid_merge), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt,
+                       I->piece_path ? (I->small_axis_cap ? kAxisCapSmall : kAxisCapLarge) : 0u);
   } else {
     hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, F.d_params, F.rays, F.cnt);
   }
@@ -1928,6 +2571,36 @@ __global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in,
   if (threadIdx.x == 0) *d_total = carry;
 }
 
+// piece path: the step counts and the piece bounds of the rays, both scanned in one launch
+__global__ void __launch_bounds__(1024) k_scan_small2(const u32* __restrict__ in_a, u32* __restrict__ out_a, u32* __restrict__ total_a, const u32* __restrict__ in_b,
+                                                      u32* __restrict__ out_b, u32* __restrict__ total_b, const u32* __restrict__ d_n, u32 n_max) {
+  __shared__ u32 lds[16];
+  const u32 n = min(*d_n, n_max);
+  for (int which = 0; which < 2; ++which) {
+    const u32* __restrict__ in = which ? in_b : in_a;
+    u32* __restrict__ out = which ? out_b : out_a;
+    u32 carry = 0;
+    for (u32 base = 0; base < n; base += 1024 * 4) {
+      const u32 i0 = base + threadIdx.x * 4;
+      u32 v[4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = (i0 + q < n) ? in[i0 + q] : 0u;
+        sum += v[q];
+      }
+      u32 total;
+      u32 ex = carry + block_exclusive_scan<16>(sum, &total, lds);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i0 + q < n) out[i0 + q] = ex;
+        ex += v[q];
+      }
+      carry += total;
+    }
+    if (threadIdx.x == 0) *(which ? total_b : total_a) = carry;
+  }
+}
+
 static int stage_b1(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
@@ -1935,6 +2608,26 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   const u32 fh_mask = I->fh_cap - 1;
   const bool merged = I->method == COX_METHOD_MERGED;
+  if (I->piece_path) {
+    const PieceArrays PA{S.pkey[0], S.pstart[0], S.prl[0]};
+    {
+      TimedRegion t_walk(I, COX_KC_TOUCH_EMIT, s);
+      hipLaunchKernelGGL(k_scan_small2, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_records, F.rays.pbound, F.rays.piece_off,
+                         &F.cnt->n_piece_slots, &F.cnt->n_ray_slots, I->pcap);
+      if (I->small_axis_cap)
+        hipLaunchKernelGGL(k_touch_pieces<kAxisCapSmall>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.lin8, PA, I->rcap, I->piece_cap,
+                           F.cnt, I->layer->d_err);
+      else
+        hipLaunchKernelGGL(k_touch_pieces<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.lin8, PA, I->rcap, I->piece_cap,
+                           F.cnt, I->layer->d_err);
+      hipLaunchKernelGGL(k_piece_keys, dim3(1024), dim3(256), 0, s, L, S.pkey[0], I->rcap, I->piece_cap, F.cnt, S.sort_info, S.touched_slots, S.ord_info);
+    }
+    TimedRegion t_sort(I, COX_KC_RECORD_SORT, s);
+    // 4 + ceil(log2(touched blocks + 1)) key bits: one pass up to 255 touched blocks, two beyond
+    (void)radix_sort_pairs<12>(S.pkey[0], S.pstart[0], S.pkey[1], S.pstart[1], &F.cnt->n_piece_slots, I->piece_cap, std::min<u32>(I->piece_cap, 1u << 21), 0,
+                               true, 2, I->sort_rec, S.sort_info, s, S.prl[0], S.prl[1]);
+    return COX_OK;
+  }
   TimedRegion* t_walk = new TimedRegion(I, COX_KC_TOUCH_EMIT, s);
   if (merged)  // a few thousand bundles: one launch
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, &F.cnt->n_records);
@@ -1943,12 +2636,12 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
   if (merged) {
     // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
     if (I->small_axis_cap)
-      hipLaunchKernelGGL(k_touch_wave<kAxisCapSmall>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
+      hipLaunchKernelGGL(k_touch_wave<kAxisCapSmall>, dim3(I->grid_touch), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
                          I->layer->d_err, F.fh_keys, fh_mask);
     else
       hipLaunchKernelGGL(k_touch_wave<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
                          I->layer->d_err, F.fh_keys, fh_mask);
-    hipLaunchKernelGGL(k_emit_wave, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
+    hipLaunchKernelGGL(k_emit_wave, dim3(I->grid_touch), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
                        F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? 1 : 0);
   } else {
     hipLaunchKernelGGL(k_touch, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, F.cnt, I->layer->d_err, F.fh_keys, fh_mask);
@@ -1973,9 +2666,17 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &F.cnt->n_records};
   TimedRegion t(I, COX_KC_APPLY, s);
+  if (I->piece_path) {
+    const RecordView KV{{S.pkey[0], S.pkey[1]}, {nullptr, nullptr}, S.sort_info, &F.cnt->n_piece_slots};
+    const PieceView PV{{S.pkey[0], S.pkey[1]}, {S.pstart[0], S.pstart[1]}, {S.prl[0], S.prl[1]}, S.sort_info};
+    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, KV, S.blk_beg, S.blk_end, F.cnt, 0u);
+    hipLaunchKernelGGL(k_apply_pieces, dim3(16384), dim3(kPT), 0, s, F.d_params, F.rays, L, S.ord_info, PV, S.lin8, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
+                       I->layer->h_nblocks);
+    return COX_OK;
+  }
   if (I->block_apply) {
-    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt);
-    hipLaunchKernelGGL(k_apply_block, dim3(8192), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
+    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, kTileShift);
+    hipLaunchKernelGGL(k_apply_block, dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
                        I->layer->h_nblocks);
     return COX_OK;
   }
@@ -1991,6 +2692,7 @@ static const StageFn kStages[4] = {stage_a1, stage_a2, stage_b1, stage_b2};
 static int run_stage(int k, const StageCtx& c) {
   cox_integrator* I = c.I;
   hipStream_t s = I->st[k];
+  tl_frame_no = c.frame;
   if (!I->use_graphs || I->profiling) return kStages[k](c, s);
   hipGraphExec_t& gx = I->graphs[k][c.slot];
   if (!gx) {
@@ -2163,6 +2865,21 @@ static int follow_layer(cox_integrator* I) {
 // enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
 static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
   cox_layer* Lh = I->layer;
+  struct HostTimer {
+    cox_integrator* I;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~HostTimer() {
+      I->host_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+      I->host_frames += 1;
+    }
+  } host_timer{I};
+  // every frame but the previous one has been enqueued completely: the events this frame waits for (F.done of frame t-4,
+  // B.done of t-2) are recorded, and the sets frame t-2 used are not touched by the submission thread any more
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    if (I->submitter) I->submitter->wait_outstanding(1);
+    I->host_wait_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
+  }
   COX_TRY(ensure_capacity(I, n));
   COX_TRY(follow_layer(I));
   I->last = cox_frame_stats{};
@@ -2174,9 +2891,14 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   FrameSet& F = I->fs[slot];
   BundleSet& B = I->bs[slot & 1];
   RecordSet& S = I->rs[slot & 1];
-  const StageCtx ctx{I, &F, &B, &S, slot};
+  const StageCtx ctx{I, &F, &B, &S, slot, I->frame_no};
+  tl_frame_no = I->frame_no;
   // the pinned parameter slot is free once the copy of the frame that used it last (t-4) has run
-  if (F.used) COX_HIP(hipEventSynchronize(F.params_copied));
+  if (F.used) {
+    const auto w0 = std::chrono::steady_clock::now();
+    COX_HIP(hipEventSynchronize(F.params_copied));
+    I->host_wait_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
+  }
   FrameParams P = make_params(I, T, n, freespace, xyz, rgba);
   P.frame_id = ++Lh->frame_id;
   I->h_params[slot] = P;
@@ -2215,31 +2937,42 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipStreamWaitEvent(I->st[1], I->ev_a1, 0));
   }
   COX_TRY(run_stage(1, ctx));
-  COX_HIP(hipEventRecord(I->ev_a2, I->st[1]));
-  COX_HIP(hipEventRecord(B.done, I->st[1]));
+  COX_HIP(hipEventRecord(B.done, I->st[1]));  // also the hand-over to B1 (per bundle set: the submission thread may be a frame behind)
   B.used = true;
   if (I->has_producer) {  // the inputs are not read after A2: later work on the caller's stream may overwrite / free them
     COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[1]));
     COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
   }
-  // B1
-  COX_HIP(hipStreamWaitEvent(I->st[2], I->ev_a2, 0));
-  if (S.used && I->st[3] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[2], S.done, 0));  // frame t-2's B2 is done with this record set
-  COX_TRY(run_stage(2, ctx));
-  // B2
-  if (I->st[3] != I->st[2]) {
-    COX_HIP(hipEventRecord(I->ev_b1, I->st[2]));
-    COX_HIP(hipStreamWaitEvent(I->st[3], I->ev_b1, 0));
-  }
-  COX_TRY(run_stage(3, ctx));
-  COX_HIP(hipEventRecord(F.done, I->st[3]));
-  COX_HIP(hipEventRecord(S.done, I->st[3]));
-  COX_HIP(hipEventRecord(Lh->last_write, I->st[3]));
-  Lh->has_write = true;
-  F.used = true;
-  S.used = true;
-  I->last_has_counts = true;
   COX_HIP(hipGetLastError());
+  // B1, B2: on the submission thread when there is one
+  auto stage_b = [ctx]() -> int {
+    cox_integrator* I = ctx.I;
+    FrameSet& F = *ctx.F;
+    BundleSet& B = *ctx.B;
+    RecordSet& S = *ctx.S;
+    cox_layer* Lh = I->layer;
+    COX_HIP(hipStreamWaitEvent(I->st[2], B.done, 0));
+    if (S.used && I->st[3] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[2], S.done, 0));  // frame t-2's B2 is done with this record set
+    COX_TRY(run_stage(2, ctx));
+    if (I->st[3] != I->st[2]) {
+      COX_HIP(hipEventRecord(I->ev_b1, I->st[2]));
+      COX_HIP(hipStreamWaitEvent(I->st[3], I->ev_b1, 0));
+    }
+    COX_TRY(run_stage(3, ctx));
+    COX_HIP(hipEventRecord(F.done, I->st[3]));
+    COX_HIP(hipEventRecord(S.done, I->st[3]));
+    COX_HIP(hipEventRecord(Lh->last_write, I->st[3]));
+    Lh->has_write = true;
+    F.used = true;
+    S.used = true;
+    COX_HIP(hipGetLastError());
+    return COX_OK;
+  };
+  if (I->submitter)
+    I->submitter->post(stage_b);
+  else
+    COX_TRY(stage_b());
+  I->last_has_counts = true;
   return COX_OK;
 }
 
@@ -2268,12 +3001,20 @@ static int fold_counters(cox_integrator* I) {
   return COX_OK;
 }
 
-static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc, std::vector<hipEvent_t>* pool) {
+// COX_TIMELINE=<file>: every timed region as "class start_ms end_ms" relative to the moment profiling was switched on
+// (hipEventElapsedTime works across streams) -- how the stages of neighbouring frames overlap, without a profiler attached
+static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* ms_acc, uint64_t* n_acc, std::vector<hipEvent_t>* pool, int cls = -1,
+                         hipEvent_t ref = nullptr, FILE* timeline = nullptr) {
   for (auto& ev : evs) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
       *ms_acc += ms;
       *n_acc += 1;
+    }
+    if (timeline && ref) {
+      float a = 0.0f, b = 0.0f;
+      if (hipEventElapsedTime(&a, ref, ev.first) == hipSuccess && hipEventElapsedTime(&b, ref, ev.second) == hipSuccess)
+        fprintf(timeline, "%d %.4f %.4f\n", cls, a, b);
     }
     pool->push_back(ev.first);
     pool->push_back(ev.second);
@@ -2292,7 +3033,9 @@ static int integrator_finish(cox_integrator* I) {
     COX_HIP(hipMemset(I->layer->d_err, 0, sizeof(u32)));
     COX_HIP(hipDeviceSynchronize());  // default-stream memset: the engine's streams would not wait for it
   }
-  for (int k = 0; k < COX_KERNEL_CLASSES; ++k) drain_events(I->class_events[k], &I->class_ms[k], &I->class_regions[k], &I->event_pool);
+  for (int k = 0; k < COX_KERNEL_CLASSES; ++k)
+    drain_events(I->class_events[k], &I->class_ms[k], &I->class_regions[k], &I->event_pool[event_pool_of(I, k)], k, I->timeline_ref, I->timeline);
+  if (I->timeline) fflush(I->timeline);
   return err_bits_to_status(lerr);
 }
 
@@ -2337,13 +3080,21 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   // stage graphs: measured slightly slower than eager launches here (2 936 vs 3 117 frames/s), so opt-in
   I->use_graphs = std::getenv("COX_GRAPH") != nullptr && std::getenv("COX_NO_GRAPH") == nullptr;
   I->block_apply = !(std::getenv("COX_APPLY") && std::string(std::getenv("COX_APPLY")) == "records");
+  // COX_APPLY=pieces: merged without anti-grazing walks, sorts and applies PIECES instead of records (k_touch_pieces / k_apply_pieces).
+  // Bit-identical and covered by the parity tests, but not the default: the piece sort is 2.3x cheaper than the record sort at
+  // 1 cm, the piece apply 1.75x dearer than the record apply -- even at 1 cm, slower at 2 cm and 5 cm
+  if (const char* e = std::getenv("COX_GRID_APPLY")) I->grid_apply = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("COX_GRID_MERGE")) I->grid_merge = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("COX_GRID_TOUCH")) I->grid_touch = std::max(1, std::atoi(e));
+  I->piece_path = method == COX_METHOD_MERGED && !cfg->enable_anti_grazing && std::getenv("COX_APPLY") && std::string(std::getenv("COX_APPLY")) == "pieces";
   int st = COX_OK;
   auto ev = [&](hipEvent_t* e) {
     if (st == COX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
   };
-  // The hardware runs at most two of these kernels side by side (measured: profiles/), so two
-  // streams (ray generation | layer update) give all the overlap there is; COX_STREAMS=4 puts every stage on its own.
-  I->n_streams = (std::getenv("COX_STREAMS") && std::atoi(std::getenv("COX_STREAMS")) == 4) ? 4 : 2;
+  // Every stage on a stream of its own: a frame's stream is a chain of ~13 small kernels with a few microseconds between
+  // them, and the frame rate at 5 cm is the length of the longest chain (measured with COX_TIMELINE):
+  // four chains of a quarter of the work give 6.0 k frames/s where two (ray generation | layer update, COX_STREAMS=2) give 5.4 k.
+  I->n_streams = (std::getenv("COX_STREAMS") && std::atoi(std::getenv("COX_STREAMS")) == 2) ? 2 : 4;
   if (method == COX_METHOD_FAST) I->n_streams = 2;  // front | record stage (graphs, if enabled, cover the record stage only)
   for (int k = 0; k < 4; ++k) {
     if ((I->n_streams == 2 && (k & 1)) || (I->n_streams == 1 && k > 0)) {
@@ -2412,6 +3163,15 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     cox_integrator_destroy(I);
     return st;
   }
+  if (method != COX_METHOD_FAST && !(std::getenv("COX_SUBMIT_THREAD") && std::atoi(std::getenv("COX_SUBMIT_THREAD")) == 0)) {
+    I->submitter = new (std::nothrow) Submitter();
+    if (I->submitter) {
+      I->submitter->device = layer->device;
+      I->submitter->th = std::thread([sub = I->submitter] { sub->run(); });
+      std::lock_guard<std::mutex> lk(g_submitters_mutex);
+      g_submitters.push_back(I->submitter);
+    }
+  }
   *out = I;
   return COX_OK;
 }
@@ -2425,13 +3185,30 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   }
   (void)hipSetDevice(I->layer->device);
   (void)sync_all(I);
+  if (I->submitter) {
+    {
+      std::lock_guard<std::mutex> lk(g_submitters_mutex);
+      g_submitters.erase(std::remove(g_submitters.begin(), g_submitters.end(), I->submitter), g_submitters.end());
+    }
+    {
+      std::lock_guard<std::mutex> lk(I->submitter->m);
+      I->submitter->stop = true;
+    }
+    I->submitter->cv_job.notify_all();
+    if (I->submitter->th.joinable()) I->submitter->th.join();
+    delete I->submitter;
+    I->submitter = nullptr;
+  }
   drop_graphs(I);
   for (auto& evs : I->class_events)
     for (auto& e : evs) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
-  for (hipEvent_t e : I->event_pool) (void)hipEventDestroy(e);
+  for (auto& pool : I->event_pool)
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+  if (I->timeline_ref) (void)hipEventDestroy(I->timeline_ref);
+  if (I->timeline) fclose(I->timeline);
   std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
                              I->scanws_f.block_sums};
@@ -2451,7 +3228,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     const RayArrays& R = F.rays;
     for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
                     static_cast<void*>(R.flags), static_cast<void*>(R.key), static_cast<void*>(R.nsteps), static_cast<void*>(R.rec_off),
-                    static_cast<void*>(F.fh_keys), static_cast<void*>(F.cnt), static_cast<void*>(F.d_params)})
+                    static_cast<void*>(R.pbound), static_cast<void*>(R.piece_off), static_cast<void*>(R.q), static_cast<void*>(F.fh_keys), static_cast<void*>(F.cnt), static_cast<void*>(F.d_params)})
       ptrs.push_back(p);
     events.push_back(F.done);
     events.push_back(F.params_copied);
@@ -2465,8 +3242,9 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (RecordSet& S : I->rs) {
     for (void* p : {static_cast<void*>(S.rec_key[0]), static_cast<void*>(S.rec_key[1]), static_cast<void*>(S.rec_ray[0]), static_cast<void*>(S.rec_ray[1]),
                     static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots), static_cast<void*>(S.ord_info),
-                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end),
-                    static_cast<void*>(S.sort_info)})
+                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end), static_cast<void*>(S.lin8), static_cast<void*>(S.pkey[0]),
+                    static_cast<void*>(S.pkey[1]), static_cast<void*>(S.pstart[0]), static_cast<void*>(S.pstart[1]), static_cast<void*>(S.prl[0]),
+                    static_cast<void*>(S.prl[1]), static_cast<void*>(S.sort_info)})
       ptrs.push_back(p);
     events.push_back(S.done);
   }
@@ -2482,7 +3260,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
 }
 
 int cox_integrate_points_dev(cox_integrator_t* I, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace) {
-  COX_ENTRY();
+  COX_ENTRY_NO_DRAIN();
   if (!I || !T_G_C || (n && !xyz_dev) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   if (I->proj) return cox_proj_integrate(I->proj, T_G_C, xyz_dev, n, 0);
@@ -2500,7 +3278,7 @@ int cox_integrate_points_ex(cox_integrator_t* I, const float T_G_C[7], const flo
 }
 
 int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
-  COX_ENTRY();
+  COX_ENTRY_NO_DRAIN();
   if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
@@ -2515,7 +3293,7 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
 }
 
 int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4]) {
-  COX_ENTRY();
+  COX_ENTRY_NO_DRAIN();
   if (!I || !T_G_C || !depth_dev || !K || w <= 0 || h <= 0 || static_cast<uint64_t>(w) * h > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   if (I->proj) return COX_ERR_UNSUPPORTED;  // the projective integrator takes point clouds (it builds its own range image)
   COX_HIP(hipSetDevice(I->layer->device));
@@ -2567,6 +3345,15 @@ int cox_integrator_set_profiling(cox_integrator_t* I, int on) {
   if (!I) return COX_ERR_INVALID_ARG;
   I->profiling = on > 0;
   I->profile_every = on > 1 ? static_cast<u32>(on) : 1u;
+  if (on > 0 && !I->proj && !I->timeline && std::getenv("COX_TIMELINE")) {
+    I->timeline = fopen(std::getenv("COX_TIMELINE"), "a");
+    if (I->timeline && hipEventCreate(&I->timeline_ref) == hipSuccess) {
+      COX_HIP(hipSetDevice(I->layer->device));
+      COX_TRY(sync_all(I));
+      COX_HIP(hipEventRecord(I->timeline_ref, I->st[0]));
+      fprintf(I->timeline, "# integrator %p method %d\n", static_cast<void*>(I), I->method);
+    }
+  }
   return COX_OK;
 }
 
@@ -2618,6 +3405,19 @@ int cox_integrator_stage_times(cox_integrator_t* I, double ms[2], uint64_t launc
       I->class_regions[k] = 0;
     }
   return st;
+}
+
+int cox_integrator_host_time(cox_integrator_t* I, double* ms_total, uint64_t* frames, int reset) {
+  COX_ENTRY();
+  if (!I || !ms_total || !frames) return COX_ERR_INVALID_ARG;
+  *ms_total = static_cast<double>(I->host_ns - I->host_wait_ns) * 1e-6;  // enqueueing only: waits for a free slot are the GPU's time
+  *frames = I->host_frames;
+  if (reset) {
+    I->host_ns = 0;
+    I->host_wait_ns = 0;
+    I->host_frames = 0;
+  }
+  return COX_OK;
 }
 
 int cox_integrator_class_times(cox_integrator_t* I, double ms[COX_KERNEL_CLASSES], uint64_t regions[COX_KERNEL_CLASSES], int reset) {

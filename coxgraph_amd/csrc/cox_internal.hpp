@@ -90,7 +90,16 @@ static inline void cox_clear_stale_hip_error(const char* where) {
     if (verbose) fprintf(stderr, "[coxgraph_hip] %s: cleared stale HIP error left by an earlier call: %s\n", where, hipGetErrorString(e));
   }
 }
-#define COX_ENTRY() cox_clear_stale_hip_error(__func__)
+// Integrators hand the second half of every frame (touch .. apply) to a submission thread of their own (cox_integrator.hip):
+// a frame that cox_integrate_* has returned from may not be fully ENQUEUED yet.  Every other entry point therefore first
+// waits until all such threads have caught up -- then stream / event / device synchronisation sees all the work, as before.
+void cox_drain_submitters();
+#define COX_ENTRY()                         \
+  do {                                      \
+    cox_clear_stale_hip_error(__func__);    \
+    cox_drain_submitters();                 \
+  } while (0)
+#define COX_ENTRY_NO_DRAIN() cox_clear_stale_hip_error(__func__)
 
 // the layer an integrator writes to (cox_integrator is private to cox_integrator.hip)
 cox_layer* cox_internal_integrator_layer(cox_integrator_t* integ);

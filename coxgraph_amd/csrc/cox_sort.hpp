@@ -258,6 +258,7 @@ __device__ __forceinline__ u64 match_digit(u32 digit, bool valid, u32 bits) {
 
 template <int RB>
 __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0, u32* __restrict__ v0, u32* __restrict__ k1, u32* __restrict__ v1,
+                                                           u32* __restrict__ x0, u32* __restrict__ x1 /* optional second value array */,
                                                            const u32* __restrict__ d_n, u32 n_max, int pass, const SortInfo* __restrict__ info, int host_bits,
                                                            const u32* __restrict__ offsets, u32 tiles_cap, u32* __restrict__ totals) {
   __shared__ u32 base[kRsWaves][1u << RB];  // first per-wave digit counts, then per-wave running output positions
@@ -273,6 +274,9 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
   const u32* vals_in = (pass & 1) ? v1 : v0;
   u32* keys_out = (pass & 1) ? k0 : k1;
   u32* vals_out = (pass & 1) ? v0 : v1;
+  const u32* xtra_in = (pass & 1) ? x1 : x0;
+  u32* xtra_out = (pass & 1) ? x0 : x1;
+  const bool has_x = x0 != nullptr;
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 tshift = rs_tile_shift(n);
   const u32 tile_elems = static_cast<u32>(kRsTile) << tshift;
@@ -308,10 +312,11 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
     for (u32 r = 0; r < rounds; ++r) {
       const u64 i = wstart + static_cast<u64>(r) * 64 + lane;
       const bool valid = i < n;
-      u32 key = 0, val = 0;
+      u32 key = 0, val = 0, xv = 0;
       if (valid) {
         key = keys_in[i];
         val = vals_in[i];
+        if (has_x) xv = xtra_in[i];
       }
       const u32 digit = (key >> shift) & (kDigits - 1);
       const u64 peers = match_digit<RB>(digit, valid, bits);
@@ -320,6 +325,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_scatter(u32* __restrict__ k0,
         const u32 pos = my_base[digit] + static_cast<u32>(__popcll(lower));
         keys_out[pos] = key;
         vals_out[pos] = val;
+        if (has_x) xtra_out[pos] = xv;
       }
       wave_lds_handover();
       if (valid && lower == 0ull) my_base[digit] += static_cast<u32>(__popcll(peers));  // group leader
@@ -339,13 +345,14 @@ static inline u32 sort_num_tiles(u64 n) { return static_cast<u32>((n + kRsTile -
 static inline size_t sort_counts_words(u32 tiles_cap) { return static_cast<size_t>(tiles_cap) << kRsMaxDigitBits; }
 static inline size_t sort_totals_words() { return static_cast<size_t>(kRsMaxPasses) << kRsMaxDigitBits; }
 
+// (x0, x1: an optional second value array that travels with the pairs.)
 // Sorts (k0,v0) by key bits [0, nbits) in ceil(nbits / RB) passes of equal width (rs_pass_digits).  Buffers ping-pong;
 // the buffer that holds the result is returned when nbits is known on the host (bits_on_device == false).  Otherwise
 // nbits is read from info->nbits (written by an earlier kernel of the frame), max_passes passes are enqueued (surplus
 // ones exit at once), the result buffer is reported in info->parity (device) and -1 is returned.  RB = 11 or 12.
 template <int RB>
 static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32* d_n, u32 n_max, u32 n_hint, int host_bits, bool bits_on_device,
-                                   int max_passes, const SortWorkspace& ws, SortInfo* info, hipStream_t s) {
+                                   int max_passes, const SortWorkspace& ws, SortInfo* info, hipStream_t s, u32* x0 = nullptr, u32* x1 = nullptr) {
   static_assert(RB >= 6 && RB <= static_cast<int>(kRsMaxDigitBits), "digit width");
   const u32 nt = sort_num_tiles(n_hint ? n_hint : 1);
   const u32 grid = nt < 1 ? 1 : (nt > 8192 ? 8192 : nt);
@@ -357,7 +364,7 @@ static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32
     u32* totals = ws.totals + (static_cast<size_t>(p) << kRsMaxDigitBits);
     hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
     hipLaunchKernelGGL(k_rs_offsets<RB>, dim3((1u << RB) / 64u), dim3(kRsOffThreads), 0, s, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
-    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, x0, x1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
   }
   return bits_on_device ? -1 : (passes & 1);
 }

@@ -198,6 +198,14 @@ int cox_integrator_kernel_time(cox_integrator_t* integ, double* apply_ms, uint64
  * frame), [1] = the TSDF update stage (k_apply_eval + k_apply_long) */
 int cox_integrator_stage_times(cox_integrator_t* integ, double ms[2], uint64_t launches[2], int reset);
 
+/*
+ * Host time the caller's thread spends enqueueing inside the cox_integrate_* calls of this integrator (waits for a free frame slot excluded):
+ * at 5 cm the stream is bound by the host's launch rate, not by the GPU, and the second half of every
+ * frame is enqueued by a submission thread of the integrator (COX_SUBMIT_THREAD=0 turns it off).  No reference counterpart
+ * (measurement only).
+ */
+int cox_integrator_host_time(cox_integrator_t* integ, double* ms_total, uint64_t* frames, int reset);
+
 /* the same for every kernel class of a frame: ms[k] = accumulated HIP-event time of the regions of class k since the last
  * reset, regions[k] = how many regions that is (one region = the consecutive launches of that class in one frame; the
  * sweeps of the fast integrator are one region per round) */
