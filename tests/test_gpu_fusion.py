@@ -83,6 +83,22 @@ def test_simple_full_frame_5cm_parity(hip, oracle):
     assert rep["err_d"] <= TOL and rep["n_diff_w"] == 0
 
 
+@pytest.mark.parametrize("select", ["pieces", "records"])
+@pytest.mark.parametrize("voxel,sub", [(0.10, 1), (0.05, 1), (0.02, 3)])
+def test_alternative_layer_update_paths_are_bit_identical(hip, oracle, monkeypatch, select, voxel, sub):
+    """COX_APPLY (read when an integrator is created) selects the other two implementations of the layer-update half of a
+    merged frame: `pieces` (k_touch_pieces / k_apply_pieces: (ray, tile) runs instead of records) and `records` (full record
+    sort + per-record kernels, round 1).  Same oracle, same bar as the default tile apply."""
+    monkeypatch.setenv("COX_APPLY", select)
+    la, _, sa = run_frames(hip, method="merged", voxel=voxel, frames=[0, 1, 2, 40], subsample=sub, capacity_blocks=40000 if voxel < 0.05 else 8192)
+    monkeypatch.delenv("COX_APPLY")
+    lb, _, sb = run_frames(oracle, method="merged", voxel=voxel, frames=[0, 1, 2, 40], subsample=sub, capacity_blocks=40000 if voxel < 0.05 else 8192)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(select, voxel, rep)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
 def test_fine_voxels_2cm(hip, oracle):
     (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.02, frames=[0, 5], subsample=3, capacity_blocks=40000)
     compare_stats(sa, sb)
