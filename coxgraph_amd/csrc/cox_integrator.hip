@@ -54,7 +54,6 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 err;
   u32 n_depth_points;
   u32 n_sorted_valid;  // valid points as seen in the sorted bundling keys (merged)
-  u32 ticket_bounds;   // arrival counter of k_bundle_count (the last workgroup scans the tile counts)
   u32 n_piece_slots;   // piece path: sum of the rays' piece bounds = slots of the piece arrays in use
   // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
   // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
@@ -267,18 +266,18 @@ struct BundleView {
 };
 // Bundle boundaries in two launches (round 1 used five: head flags, a three-kernel scan, starts).  A head is a sorted position
 // whose key differs from its predecessor's; a bundle's ordinal is the number of heads before it.
-//   k_bundle_count   per tile of 2048 positions: number of heads; the workgroup that arrives last scans the tile counts
-//                    (a frame has ~150 tiles) and publishes the number of bundles
-//   k_bundle_starts  per tile: heads again, in-tile exclusive scan, bstart[tile base + rank] = position
+//   k_bundle_count   per tile of 2048 positions: number of heads
+//   k_bundle_starts  per tile: its base = sum of the counts of the tiles before it (every workgroup adds them up itself --
+//                    a frame has ~150 tiles; a ticketed "last workgroup scans" tail took 12 us, this takes none), heads
+//                    again, in-tile exclusive scan, bstart[base + rank] = position; the last tile publishes the bundle count
 constexpr u32 kBoundTile = 2048;
 __device__ __forceinline__ bool bundle_head(const u32* __restrict__ skey, u32 i, u32 n) {
   if (i >= n) return false;
   const u32 k = skey[i];
   return k != kInvalid && (i == 0 || skey[i - 1] != k);
 }
-__global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ tile_sums, Counters* cnt) {
-  __shared__ u32 lds[16];
-  __shared__ u32 last;
+__global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ tile_sums) {
+  __shared__ u32 lds[4];
   const u32 n = Pp->n_points;
   const u32* __restrict__ skey = V.key[V.info->parity & 1u];
   const u32 n_tiles = (n + kBoundTile - 1) / kBoundTile;
@@ -290,33 +289,22 @@ __global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restr
     (void)block_exclusive_scan<4>(c, &tot, lds);
     if (threadIdx.x == 0) tile_sums[tile] = tot;
   }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = (atomicAdd(&cnt->ticket_bounds, 1u) == gridDim.x - 1u) ? 1u : 0u;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  u32 carry = 0;
-  for (u32 base = 0; base < n_tiles; base += 256) {
-    const u32 i = base + threadIdx.x;
-    const u32 v = (i < n_tiles) ? __hip_atomic_load(&tile_sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    u32 tot;
-    const u32 ex = block_exclusive_scan<4>(v, &tot, lds);
-    if (i < n_tiles) tile_sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    cnt->n_rays = carry;  // number of bundles
-    cnt->n_ray_slots = carry;
-  }
 }
-__global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ tile_base, u32* __restrict__ bstart,
+__global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __restrict__ Pp, BundleView V, const u32* __restrict__ tile_sums, u32* __restrict__ bstart,
                                                        Counters* cnt) {
-  __shared__ u32 lds[4];
+  __shared__ u32 lds[4], lds2[4];
   const u32 n = Pp->n_points;
   const u32* __restrict__ skey = V.key[V.info->parity & 1u];
   const u32 n_tiles = (n + kBoundTile - 1) / kBoundTile;
+  if (n_tiles == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    cnt->n_rays = 0;
+    cnt->n_ray_slots = 0;
+  }
   for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    u32 below = 0;
+    for (u32 t = threadIdx.x; t < tile; t += 256) below += tile_sums[t];
+    u32 base;
+    (void)block_exclusive_scan<4>(below, &base, lds2);
     // thread t owns the 8 consecutive positions [tile * 2048 + 8 t, + 8)
     const u32 i0 = tile * kBoundTile + threadIdx.x * 8;
     bool h[8];
@@ -327,12 +315,16 @@ __global__ void __launch_bounds__(256) k_bundle_starts(const FrameParams* __rest
       c += h[q] ? 1u : 0u;
     }
     u32 tot;
-    u32 rank = tile_base[tile] + block_exclusive_scan<4>(c, &tot, lds);
+    u32 rank = base + block_exclusive_scan<4>(c, &tot, lds);
 #pragma unroll
     for (u32 q = 0; q < 8; ++q) {
       const u32 i = i0 + q;
       if (h[q]) bstart[rank++] = i;
       if (i < n && skey[i] != kInvalid && (i + 1 == n || skey[i + 1] == kInvalid)) cnt->n_sorted_valid = i + 1;  // invalid keys sort last: one writer
+    }
+    if (tile + 1 == n_tiles && threadIdx.x == 0) {
+      cnt->n_rays = base + tot;  // number of bundles
+      cnt->n_ray_slots = base + tot;
     }
   }
 }
@@ -2533,9 +2525,9 @@ static int stage_a2(const StageCtx& c, hipStream_t s) {
   const u32 n = I->pcap;
   if (I->method == COX_METHOD_MERGED) {
     BundleView V{{B.skey[0], B.skey[1]}, {B.sval[0], B.sval[1]}, B.sort_info};
-    // bundle boundaries: heads per tile (+ their scan by the last workgroup), then the starts
+    // bundle boundaries: heads per tile, then the starts
     const dim3 gt(std::max<u32>(1, (n + kBoundTile - 1) / kBoundTile));
-    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head, F.cnt);
+    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head);
     hipLaunchKernelGGL(k_bundle_starts, gt, dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
     TimedRegion t(I, COX_KC_MERGE, s);
     hipLaunchKernelGGL(k_bundle_merge, dim3(I->grid_merge), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt,

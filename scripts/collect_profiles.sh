@@ -20,6 +20,16 @@ for M in merged fast; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${M}_pmc_write" -o p -- python3 bench.py $PMC > "$OUT/${M}_pmc_write.log" 2>&1
   echo "$M pmc passes done"
 done
+# fine voxels: bench line + one-frame-in-flight kernel statistics
+FINE="--cpu-frames 0 --reg-iters 0 --other-frames 0 --pcie-frames 0 --no-ramp"
+python3 bench.py --voxel 0.02 --steps 60 --warmup 10 $FINE > "$OUT/bench_line_2cm.json" 2> "$OUT/bench_line_2cm.err"
+python3 bench.py --voxel 0.01 --steps 40 --warmup 10 $FINE > "$OUT/bench_line_1cm.json" 2> "$OUT/bench_line_1cm.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged_serial_2cm" -o t -- python3 bench.py --method merged --voxel 0.02 --steps 40 --warmup 10 --serial --no-events --no-profile-pass $FINE > "$OUT/merged_serial_2cm.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged_serial_1cm" -o t -- python3 bench.py --method merged --voxel 0.01 --steps 30 --warmup 10 --serial --no-events --no-profile-pass $FINE > "$OUT/merged_serial_1cm.log" 2>&1
+rm -f "$OUT"/merged_serial_?cm/*kernel_trace.csv
+echo "fine voxel runs done"
+# where the kernel classes of neighbouring frames sit in time, without a profiler attached (COX_TIMELINE: HIP events)
+COX_TIMELINE="$OUT/stage_timeline_5cm.txt" python3 bench.py --steps 60 --warmup 20 --cpu-frames 0 --reg-iters 0 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp > "$OUT/stage_timeline_5cm.log" 2>&1
 # keep what comes back small: the per-dispatch traces of the async runs are only needed for the concurrency timeline of merged
 find "$OUT" -name "*_agent_info.csv" -delete
 ls -la "$OUT" "$OUT"/*/ | head -60

@@ -44,6 +44,21 @@ for m in ("merged", "fast"):
         copy(stats, os.path.join(P, name + ".csv"))
         head = f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --method {m} {COMMON}{flag}   ({what}; us/frame = total / {FRAMES_TRACE} frames: 20 warm-up + 300 timed)"
         open(os.path.join(P, name + ".txt"), "w").write(head + "\n" + run(os.path.join(HERE, "kstats.py"), stats, str(FRAMES_TRACE)))
+# fine voxels: one-frame-in-flight kernel statistics + the bench line of the same configuration
+for vox, frames in (("2cm", 50), ("1cm", 40)):
+    try:
+        stats = find(f"merged_serial_{vox}", "kernel_stats.csv")
+        name = f"{tag}_bench_merged_serial_{vox}_kernel_stats"
+        copy(stats, os.path.join(P, name + ".csv"))
+        head = (f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --method merged --voxel 0.0{vox[0]} --steps {frames - 10} --warmup 10 --serial --no-events "
+                f"--cpu-frames 0 --reg-iters 0 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp   (us/frame = total / {frames} frames)")
+        open(os.path.join(P, name + ".txt"), "w").write(head + "\n" + run(os.path.join(HERE, "kstats.py"), stats, str(frames)))
+        copy(os.path.join(src, f"bench_line_{vox}.json"), os.path.join(P, f"{tag}_bench_line_{vox}.json"))
+    except (SystemExit, FileNotFoundError) as e:
+        print("fine-voxel profile skipped:", vox, e)
+for extra in ("stage_timeline_5cm.txt",):
+    if os.path.exists(os.path.join(src, extra)):
+        copy(os.path.join(src, extra), os.path.join(P, f"{tag}_{extra}"))
 try:
     open(os.path.join(P, f"{tag}_timeline_concurrency.txt"), "w").write(
         f"# kernels in flight during the middle half of the fusion frames of: rocprofv3 --kernel-trace -- python3 bench.py --method merged {COMMON}\n" +
@@ -57,10 +72,10 @@ STEADY = 40  # frames of the PMC run that are counted: the last 40 (set-up -- a 
 
 def pmc(path, name):
     """Per kernel: summed counter and dispatch count over the LAST `STEADY` frames of the run.  A frame ends with its
-    k_apply_long dispatch (exactly one per frame, the last kernel of a frame in --serial mode)."""
+    apply dispatch (k_apply_block by default: exactly one per frame, the last kernel of a frame in --serial mode)."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_apply_long")]
+    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_apply_block", "k_apply_pieces", "k_apply_long"))]
     assert len(ends) >= STEADY + 1, len(ends)
     lo, hi = ends[-STEADY - 1] + 1, ends[-1] + 1
     acc, cnt, order = collections.defaultdict(float), collections.defaultdict(int), []
