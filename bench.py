@@ -32,10 +32,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# An integrator runs its four stages on four HIP streams; the ROCm runtime multiplexes a process's
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with torch's own streams), and two stages that land on
+# one queue run back to back: 6.1 k frames/s with 4 queues, 7.5 k with 8.  Read when the runtime initialises, so set it first.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 KERNELS_OF_CLASS = {
-    "merge": "k_bundle_merge", "apply": "k_apply_eval+k_apply_long", "bundle_hash": "fillBuffer+k_bundle_insert+k_bundle_keys",
+    "merge": "k_bundle_merge", "apply": "k_block_starts+k_apply_block", "bundle_hash": "fillBuffer+k_bundle_insert+k_bundle_keys+k_bundle_clear",
     "point_sort": "k_rs_hist/offsets/scatter<11> (points)", "touch_emit": "k_scan_small+k_touch*+k_emit*",
     "record_sort": "k_rs_hist/offsets/scatter<12> (records)", "fast_start": "k_fast_points..k_fast_rays (+ point sort)",
     "fast_visits": "k_fast_visits+visit sort+k_fast_inverse", "fast_sweeps": "k_fast_scan_tiles+k_fast_sweep (all sweeps of a frame)",

@@ -7,8 +7,13 @@ ctypes binding used by the tests and ``bench.py``.  The engine is the in-tree sh
 :func:`load_engine` raises.
 """
 import os
-from . import capi
-from .capi import Engine, Layer, Integrator, RegPoints, Registration, CoxError  # noqa: F401
+
+# Four stage streams per integrator (+ the caller's): more hardware queues than the runtime's default of 4, or stages share a
+# queue and run back to back (DESIGN.md section 6).  Only effective if the HIP runtime of this process is not initialised yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from . import capi  # noqa: E402
+from .capi import Engine, Layer, Integrator, RegPoints, Registration, CoxError  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcoxgraph_hip.so")

@@ -2074,7 +2074,9 @@ __global__ void __launch_bounds__(256) k_selftest_division(u64 n, u64 seed, u32*
 // once per buffer combination into a HIP graph (4 stages x 4 combinations) and replayed -- one graph launch instead
 // of ~12 kernel launches per stage, which lifts the host-side launch-rate limit (~3 000 frames/s eager).
 constexpr int kStatRing = 8;
-constexpr int kFrameSets = 4;
+constexpr int kFrameSets = 6;  // frames in flight: one per stage
+constexpr int kStageSets = 3;  // bundle sets (live H..M) and record sets (live T..U); kFrameSets is a multiple, so a frame slot fixes both
+constexpr int kNumStages = 6;  // H bundle hash | P bundling sort | M bundle boundaries + means | T offsets, touch, emit | R record partition | U apply
 
 struct FrameSet {  // lives A1 .. B2
   FrameParams* d_params = nullptr;
@@ -2082,8 +2084,9 @@ struct FrameSet {  // lives A1 .. B2
   RayArrays rays{};
   u64* fh_keys = nullptr;  // [fh_cap] keys followed by [fh_cap] first-sequence numbers (one memset)
   u32* fh_first = nullptr;
-  hipEvent_t done = nullptr;           // B2 of the frame that used this set
+  hipEvent_t done = nullptr;           // stage U of the frame that used this set
   hipEvent_t params_copied = nullptr;  // the H2D copy of the parameter block has executed (host may rewrite the pinned slot)
+  hipEvent_t hand[kNumStages - 1] = {};  // hand[k]: stage k of the frame is enqueued complete (stage k + 1 on another stream waits for it)
   bool used = false;
 };
 struct BundleSet {  // lives A1 .. A2
@@ -2191,12 +2194,12 @@ struct cox_integrator {
   FastState fast;
   cox_tsdf_config cfg;
   int method = 0;
-  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // stream of stage A1, A2, B1, B2 (st[1] == st[0], st[3] == st[2]: see create)
-  int n_streams = 2;
-  hipEvent_t ev_a1 = nullptr, ev_a2 = nullptr, ev_b1 = nullptr;  // per-frame hand-over events (re-recorded every frame)
+  hipStream_t st[kNumStages] = {};  // stream of stage H, P, M, T, R, U (2 / 4 / 6 distinct ones, equal streams adjacent: see create)
+  int n_streams = 4;
+  hipEvent_t ev_a2 = nullptr;  // fast: front -> record stage
   FrameSet fs[kFrameSets];
-  BundleSet bs[2];
-  RecordSet rs[2];
+  BundleSet bs[kStageSets];
+  RecordSet rs[kStageSets];
   FrameParams* h_params = nullptr;  // pinned, kFrameSets entries
   u32 pcap = 0, rcap = 0, fh_cap = 0;
   u32 steps_max = 0;  // upper bound of a ray's step count for this configuration
@@ -2227,7 +2230,7 @@ struct cox_integrator {
   bool last_has_counts = false;
   // stage graphs: [stage][frame set index] (the bundle / record set index is the frame set index & 1)
   bool use_graphs = true;
-  hipGraphExec_t graphs[4][kFrameSets] = {};
+  hipGraphExec_t graphs[kNumStages][kFrameSets] = {};
   // timing of individual kernels (bench roofline); forces eager launches
   bool profiling = false;
   u32 profile_every = 1;  // time the kernels of every n-th frame
@@ -2280,7 +2283,7 @@ static int sync_all(cox_integrator* I) {
     const int st = I->submitter->take_status();
     if (st != COX_OK) return st;
   }
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
   return COX_OK;
 }
@@ -2477,7 +2480,7 @@ struct TimedRegion {
   }
 };
 
-// ---- the four stages; identical whether launched eagerly or captured into a graph: no argument depends on the frame ----
+// ---- the six stages; identical whether launched eagerly or captured into a graph: no argument depends on the frame ----
 struct StageCtx {
   cox_integrator* I;
   FrameSet* F;
@@ -2492,7 +2495,7 @@ static LayerView layer_view(const cox_layer* Lh) {
 }
 static int points_sort_passes(const cox_integrator* I) { return (ceil_log2(next_pow2(static_cast<u64>(I->pcap) + 1)) + 1 + 10) / 11; }
 
-static int stage_a1(const StageCtx& c, hipStream_t s) {
+static int stage_hash(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   BundleSet& B = *c.B;
@@ -2512,13 +2515,22 @@ static int stage_a1(const StageCtx& c, hipStream_t s) {
       hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
       if (self_clean) hipLaunchKernelGGL(k_bundle_clear, grid_for(n), dim3(256), 0, s, F.d_params, B.pslot, F.fh_keys, F.fh_first);
     }
+  }
+  return COX_OK;
+}
+static int stage_point_sort(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  if (I->method == COX_METHOD_MERGED) {
+    const u32 n = I->pcap;
     TimedRegion t(I, COX_KC_POINT_SORT, s);
     (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I), I->sort_pts,
                                B.sort_info, s);
   }
   return COX_OK;
 }
-static int stage_a2(const StageCtx& c, hipStream_t s) {
+static int stage_merge(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   BundleSet& B = *c.B;
@@ -2593,7 +2605,7 @@ __global__ void __launch_bounds__(1024) k_scan_small2(const u32* __restrict__ in
   }
 }
 
-static int stage_b1(const StageCtx& c, hipStream_t s) {
+static int stage_touch(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   RecordSet& S = *c.S;
@@ -2614,13 +2626,9 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
                            F.cnt, I->layer->d_err);
       hipLaunchKernelGGL(k_piece_keys, dim3(1024), dim3(256), 0, s, L, S.pkey[0], I->rcap, I->piece_cap, F.cnt, S.sort_info, S.touched_slots, S.ord_info);
     }
-    TimedRegion t_sort(I, COX_KC_RECORD_SORT, s);
-    // 4 + ceil(log2(touched blocks + 1)) key bits: one pass up to 255 touched blocks, two beyond
-    (void)radix_sort_pairs<12>(S.pkey[0], S.pstart[0], S.pkey[1], S.pstart[1], &F.cnt->n_piece_slots, I->piece_cap, std::min<u32>(I->piece_cap, 1u << 21), 0,
-                               true, 2, I->sort_rec, S.sort_info, s, S.prl[0], S.prl[1]);
     return COX_OK;
   }
-  TimedRegion* t_walk = new TimedRegion(I, COX_KC_TOUCH_EMIT, s);
+  TimedRegion t_walk(I, COX_KC_TOUCH_EMIT, s);
   if (merged)  // a few thousand bundles: one launch
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, &F.cnt->n_records);
   else
@@ -2640,8 +2648,19 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
                        F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? 1 : 0);
   }
-  delete t_walk;
+  return COX_OK;
+}
+static int stage_record_sort(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  RecordSet& S = *c.S;
   TimedRegion t_sort(I, COX_KC_RECORD_SORT, s);
+  if (I->piece_path) {
+    // 4 + ceil(log2(touched blocks + 1)) key bits: one pass up to 255 touched blocks, two beyond
+    (void)radix_sort_pairs<12>(S.pkey[0], S.pstart[0], S.pkey[1], S.pstart[1], &F.cnt->n_piece_slots, I->piece_cap, std::min<u32>(I->piece_cap, 1u << 21), 0,
+                               true, 2, I->sort_rec, S.sort_info, s, S.prl[0], S.prl[1]);
+    return COX_OK;
+  }
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
   // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
   // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
@@ -2651,7 +2670,7 @@ static int stage_b1(const StageCtx& c, hipStream_t s) {
                              I->block_apply ? 2 : 3, I->sort_rec, S.sort_info, s);
   return COX_OK;
 }
-static int stage_b2(const StageCtx& c, hipStream_t s) {
+static int stage_apply(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   RecordSet& S = *c.S;
@@ -2678,7 +2697,7 @@ static int stage_b2(const StageCtx& c, hipStream_t s) {
   return COX_OK;
 }
 typedef int (*StageFn)(const StageCtx&, hipStream_t);
-static const StageFn kStages[4] = {stage_a1, stage_a2, stage_b1, stage_b2};
+static const StageFn kStages[kNumStages] = {stage_hash, stage_point_sort, stage_merge, stage_touch, stage_record_sort, stage_apply};
 
 // launch stage k of the frame in ctx on its stream: replay its graph (capturing it first if needed) or go eager
 static int run_stage(int k, const StageCtx& c) {
@@ -2820,8 +2839,9 @@ static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
   // buffers) run beside it
   COX_HIP(hipEventRecord(I->ev_a2, s));
   COX_HIP(hipStreamWaitEvent(s_back, I->ev_a2, 0));
-  COX_TRY(run_stage(2, c));  // stage_b1 on st[2] (== s_back); replayed as a captured graph when COX_GRAPH is set
-  COX_TRY(run_stage(3, c));  // stage_b2 on st[3] == st[2]
+  COX_TRY(run_stage(3, c));  // touch / emit, record partition, apply on st[3] == st[4] == st[5] (== s_back); replayed as
+  COX_TRY(run_stage(4, c));  // captured graphs when COX_GRAPH is set
+  COX_TRY(run_stage(5, c));
   return COX_OK;
 }
 
@@ -2865,8 +2885,8 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
       I->host_frames += 1;
     }
   } host_timer{I};
-  // every frame but the previous one has been enqueued completely: the events this frame waits for (F.done of frame t-4,
-  // B.done of t-2) are recorded, and the sets frame t-2 used are not touched by the submission thread any more
+  // every frame but the previous one has been enqueued completely: the events this frame waits for (F.done of frame t-6,
+  // B.done of t-3) are recorded, and the sets frame t-3 used are not touched by the submission thread any more
   {
     const auto w0 = std::chrono::steady_clock::now();
     if (I->submitter) I->submitter->wait_outstanding(1);
@@ -2881,8 +2901,8 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   I->frame_no += 1;
   const int slot = static_cast<int>(I->frame_no % kFrameSets);
   FrameSet& F = I->fs[slot];
-  BundleSet& B = I->bs[slot & 1];
-  RecordSet& S = I->rs[slot & 1];
+  BundleSet& B = I->bs[slot % kStageSets];
+  RecordSet& S = I->rs[slot % kStageSets];
   const StageCtx ctx{I, &F, &B, &S, slot, I->frame_no};
   tl_frame_no = I->frame_no;
   // the pinned parameter slot is free once the copy of the frame that used it last (t-4) has run
@@ -2900,17 +2920,17 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipStreamWaitEvent(I->st[0], I->ev_producer, 0));
   }
   if (I->method == COX_METHOD_FAST) {  // front (sets, sweeps) on st[0], record stage on st[2], see fast_frame
-    if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-4 is done with this frame set
-    if (S.used) COX_HIP(hipStreamWaitEvent(I->st[0], S.done, 0));  // frame t-2's record stage is done with this record set (the visit sort borrows it)
-    COX_TRY(fast_frame(ctx, I->st[0], I->st[2]));
+    if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-6 is done with this frame set
+    if (S.used) COX_HIP(hipStreamWaitEvent(I->st[0], S.done, 0));  // frame t-3's record stage is done with this record set (the visit sort borrows it)
+    COX_TRY(fast_frame(ctx, I->st[0], I->st[3]));
     COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
     if (I->has_producer) {  // the inputs are read by the front only
       COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[0]));
       COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
     }
-    COX_HIP(hipEventRecord(F.done, I->st[2]));
-    COX_HIP(hipEventRecord(S.done, I->st[2]));
-    COX_HIP(hipEventRecord(Lh->last_write, I->st[2]));
+    COX_HIP(hipEventRecord(F.done, I->st[5]));
+    COX_HIP(hipEventRecord(S.done, I->st[5]));
+    COX_HIP(hipEventRecord(Lh->last_write, I->st[5]));
     Lh->has_write = true;
     F.used = true;
     S.used = true;
@@ -2918,42 +2938,41 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipGetLastError());
     return COX_OK;
   }
-  // A1
-  if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-4 is done with this frame set
-  if (B.used && I->st[1] != I->st[0]) COX_HIP(hipStreamWaitEvent(I->st[0], B.done, 0));  // frame t-2's A2 is done with this bundle set
-  COX_TRY(run_stage(0, ctx));
+  // stage k + 1 of a frame follows stage k: in stream order, or behind the frame slot's hand-over event when on another stream
+  auto chain = [](const StageCtx& x, int k) -> int {  // run stage k behind stage k - 1
+    cox_integrator* I = x.I;
+    if (k > 0 && I->st[k] != I->st[k - 1]) COX_HIP(hipStreamWaitEvent(I->st[k], x.F->hand[k - 1], 0));
+    COX_TRY(run_stage(k, x));
+    if (k + 1 < kNumStages && I->st[k + 1] != I->st[k]) COX_HIP(hipEventRecord(x.F->hand[k], I->st[k]));
+    return COX_OK;
+  };
+  // H, P, M (ray generation: depends on the frame's input only)
+  if (F.used && I->st[0] != I->st[5]) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-6 is done with this frame set
+  if (B.used && I->st[0] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[0], B.done, 0));  // frame t-3's merge is done with this bundle set
+  COX_TRY(chain(ctx, 0));
   COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
-  // A2
-  if (I->st[1] != I->st[0]) {
-    COX_HIP(hipEventRecord(I->ev_a1, I->st[0]));
-    COX_HIP(hipStreamWaitEvent(I->st[1], I->ev_a1, 0));
-  }
-  COX_TRY(run_stage(1, ctx));
-  COX_HIP(hipEventRecord(B.done, I->st[1]));  // also the hand-over to B1 (per bundle set: the submission thread may be a frame behind)
+  COX_TRY(chain(ctx, 1));
+  COX_TRY(chain(ctx, 2));
+  COX_HIP(hipEventRecord(B.done, I->st[2]));
   B.used = true;
-  if (I->has_producer) {  // the inputs are not read after A2: later work on the caller's stream may overwrite / free them
-    COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[1]));
+  if (I->has_producer) {  // the inputs are not read after the merge: later work on the caller's stream may overwrite / free them
+    COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[2]));
     COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
   }
   COX_HIP(hipGetLastError());
-  // B1, B2: on the submission thread when there is one
-  auto stage_b = [ctx]() -> int {
+  // T, R, U (layer update): on the submission thread when there is one
+  auto stage_b = [ctx, chain]() -> int {
     cox_integrator* I = ctx.I;
     FrameSet& F = *ctx.F;
-    BundleSet& B = *ctx.B;
     RecordSet& S = *ctx.S;
     cox_layer* Lh = I->layer;
-    COX_HIP(hipStreamWaitEvent(I->st[2], B.done, 0));
-    if (S.used && I->st[3] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[2], S.done, 0));  // frame t-2's B2 is done with this record set
-    COX_TRY(run_stage(2, ctx));
-    if (I->st[3] != I->st[2]) {
-      COX_HIP(hipEventRecord(I->ev_b1, I->st[2]));
-      COX_HIP(hipStreamWaitEvent(I->st[3], I->ev_b1, 0));
-    }
-    COX_TRY(run_stage(3, ctx));
-    COX_HIP(hipEventRecord(F.done, I->st[3]));
-    COX_HIP(hipEventRecord(S.done, I->st[3]));
-    COX_HIP(hipEventRecord(Lh->last_write, I->st[3]));
+    if (S.used && I->st[3] != I->st[5]) COX_HIP(hipStreamWaitEvent(I->st[3], S.done, 0));  // frame t-3's apply is done with this record set
+    COX_TRY(chain(ctx, 3));
+    COX_TRY(chain(ctx, 4));
+    COX_TRY(chain(ctx, 5));
+    COX_HIP(hipEventRecord(F.done, I->st[5]));
+    COX_HIP(hipEventRecord(S.done, I->st[5]));
+    COX_HIP(hipEventRecord(Lh->last_write, I->st[5]));
     Lh->has_write = true;
     F.used = true;
     S.used = true;
@@ -3083,27 +3102,48 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   auto ev = [&](hipEvent_t* e) {
     if (st == COX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
   };
-  // Every stage on a stream of its own: a frame's stream is a chain of ~13 small kernels with a few microseconds between
-  // them, and the frame rate at 5 cm is the length of the longest chain (measured with COX_TIMELINE):
-  // four chains of a quarter of the work give 6.0 k frames/s where two (ray generation | layer update, COX_STREAMS=2) give 5.4 k.
-  I->n_streams = (std::getenv("COX_STREAMS") && std::atoi(std::getenv("COX_STREAMS")) == 2) ? 2 : 4;
+  // A frame's stream is a chain of small kernels with a few microseconds between them, and the frame rate at 5 cm is the
+  // length of the longest chain (measured with COX_TIMELINE).  Frames/s at 5 / 2 / 1 cm, same box, 16
+  // hardware queues: two streams (H P M | T R U) 5 747 / - / -; four (H P | M | T R | U) 7 636 / 2 128 / 506; six (every stage
+  // its own) 4 202 / 1 949 / 531 -- past four the hand-overs between queues cost more than the shorter chains give back.
+  I->n_streams = 4;
+  if (const char* e = std::getenv("COX_STREAMS")) {
+    const int v = std::atoi(e);
+    if (v == 2 || v == 4 || v == 6) I->n_streams = v;
+  }
   if (method == COX_METHOD_FAST) I->n_streams = 2;  // front | record stage (graphs, if enabled, cover the record stage only)
-  for (int k = 0; k < 4; ++k) {
-    if ((I->n_streams == 2 && (k & 1)) || (I->n_streams == 1 && k > 0)) {
-      I->st[k] = I->st[k - 1];
-    } else if (st == COX_OK && hipStreamCreateWithFlags(&I->st[k], hipStreamNonBlocking) != hipSuccess) {
-      st = COX_ERR_NO_DEVICE;
+  {
+    // stage -> stream: 6: one each; 4: H P | M | T R | U; 2: H P M | T R U.  Equal streams are adjacent.
+    static const int kMap[3][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}};
+    const int* map = kMap[I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    // fast: its front is a chain of short sweeps with host round trips in between, and the record stage of the previous frame
+    // running beside it slows every one of them: measured with 16 hardware queues, one stream 2 393 frames/s, two streams
+    // 1 898, two streams with the front at high priority 1 952 (with the runtime's default of 4 queues the two streams mostly
+    // shared a queue and the question did not arise).  One stream it is; COX_FAST_STREAMS=2 / 3 select the other two.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int fast_mode = std::getenv("COX_FAST_STREAMS") ? std::atoi(std::getenv("COX_FAST_STREAMS")) : 1;  // 1: one stream, 2: priorities, 3: equal priorities
+    hipStream_t made[kNumStages] = {};
+    for (int k = 0; k < kNumStages; ++k) {
+      int m = map[k];
+      if (method == COX_METHOD_FAST && fast_mode == 1) m = 0;
+      if (!made[m] && st == COX_OK) {
+        const int prio = (method == COX_METHOD_FAST && fast_mode == 2) ? (m == 0 ? prio_greatest : prio_least) : 0;
+        const hipError_t e = (method == COX_METHOD_FAST && fast_mode == 2) ? hipStreamCreateWithPriority(&made[m], hipStreamNonBlocking, prio)
+                                                                             : hipStreamCreateWithFlags(&made[m], hipStreamNonBlocking);
+        if (e != hipSuccess) st = COX_ERR_NO_DEVICE;
+      }
+      I->st[k] = made[m];
     }
   }
-  ev(&I->ev_a1);
   ev(&I->ev_a2);
-  ev(&I->ev_b1);
   ev(&I->ev_producer);
   ev(&I->ev_inputs_read);
   I->layer_generation = layer->generation;
   for (FrameSet& F : I->fs) {
     ev(&F.done);
     ev(&F.params_copied);
+    for (hipEvent_t& h : F.hand) ev(&h);
     if (st == COX_OK) st = dev_realloc(&F.cnt, 1);
     if (st == COX_OK) st = dev_realloc(&F.d_params, 1);
   }
@@ -3215,7 +3255,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     for (hipEvent_t e : X.ev)
       if (e) (void)hipEventDestroy(e);
   }
-  std::vector<hipEvent_t> events = {I->ev_a1, I->ev_a2, I->ev_b1, I->ev_producer, I->ev_inputs_read};
+  std::vector<hipEvent_t> events = {I->ev_a2, I->ev_producer, I->ev_inputs_read};
   for (FrameSet& F : I->fs) {
     const RayArrays& R = F.rays;
     for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
@@ -3224,6 +3264,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
       ptrs.push_back(p);
     events.push_back(F.done);
     events.push_back(F.params_copied);
+    for (hipEvent_t h : F.hand) events.push_back(h);
   }
   for (BundleSet& B : I->bs) {
     for (void* p : {static_cast<void*>(B.pslot), static_cast<void*>(B.skey[0]), static_cast<void*>(B.skey[1]), static_cast<void*>(B.sval[0]),
@@ -3246,7 +3287,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     if (e) (void)hipEventDestroy(e);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
   if (I->h_params) (void)hipHostFree(I->h_params);
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
   delete I;
 }

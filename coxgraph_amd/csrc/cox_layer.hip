@@ -16,6 +16,7 @@
 //   sort      stable radix sort by voxel id -> per voxel, records are in canonical ray order
 //   apply     per voxel: the running weighted-mean/clamp update in exactly that order
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -76,6 +77,15 @@ const char* cox_status_string(int s) {
   }
   return "COX_ERR_?";
 }
+
+// Four stage streams per integrator: ask the runtime for more hardware queues than its default of 4 before it starts, if
+// nobody has chosen a number (stages that share a queue run back to back: 6.1 k instead of 7.5 k frames/s at 5 cm).  Runs
+// when the library is loaded; without effect when the HIP runtime of the process is already up.
+namespace {
+struct QueueHint {
+  QueueHint() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_queue_hint;
+}  // namespace
 
 int cox_device_count(void) {
   COX_ENTRY();

@@ -22,8 +22,10 @@ for M in merged fast; do
 done
 # fine voxels: bench line + one-frame-in-flight kernel statistics
 FINE="--cpu-frames 0 --reg-iters 0 --other-frames 0 --pcie-frames 0 --no-ramp"
-python3 bench.py --voxel 0.02 --steps 60 --warmup 10 $FINE > "$OUT/bench_line_2cm.json" 2> "$OUT/bench_line_2cm.err"
-python3 bench.py --voxel 0.01 --steps 40 --warmup 10 $FINE > "$OUT/bench_line_1cm.json" 2> "$OUT/bench_line_1cm.err"
+LINE="--cpu-frames 0 --reg-iters 0 --other-frames 40 --pcie-frames 0"
+python3 bench.py --voxel 0.10 --steps 100 --warmup 10 $LINE > "$OUT/bench_line_10cm.json" 2> "$OUT/bench_line_10cm.err"
+python3 bench.py --voxel 0.02 --steps 60 --warmup 10 $LINE > "$OUT/bench_line_2cm.json" 2> "$OUT/bench_line_2cm.err"
+python3 bench.py --voxel 0.01 --steps 40 --warmup 10 $LINE > "$OUT/bench_line_1cm.json" 2> "$OUT/bench_line_1cm.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged_serial_2cm" -o t -- python3 bench.py --method merged --voxel 0.02 --steps 40 --warmup 10 --serial --no-events --no-profile-pass $FINE > "$OUT/merged_serial_2cm.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged_serial_1cm" -o t -- python3 bench.py --method merged --voxel 0.01 --steps 30 --warmup 10 --serial --no-events --no-profile-pass $FINE > "$OUT/merged_serial_1cm.log" 2>&1
 rm -f "$OUT"/merged_serial_?cm/*kernel_trace.csv

@@ -56,6 +56,8 @@ for vox, frames in (("2cm", 50), ("1cm", 40)):
         copy(os.path.join(src, f"bench_line_{vox}.json"), os.path.join(P, f"{tag}_bench_line_{vox}.json"))
     except (SystemExit, FileNotFoundError) as e:
         print("fine-voxel profile skipped:", vox, e)
+if os.path.exists(os.path.join(src, "bench_line_10cm.json")):
+    copy(os.path.join(src, "bench_line_10cm.json"), os.path.join(P, f"{tag}_bench_line_10cm.json"))
 for extra in ("stage_timeline_5cm.txt",):
     if os.path.exists(os.path.join(src, extra)):
         copy(os.path.join(src, extra), os.path.join(P, f"{tag}_{extra}"))

@@ -348,8 +348,9 @@ def test_config4_shape_1280x720_2cm(hip, oracle):
 
 
 def test_one_centimetre_voxels(hip, oracle):
-    """BASELINE configs[4] voxel size (extrapolated ray limits): thousands of blocks, ~1e6 voxels per frame."""
-    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.01, frames=[0], subsample=2, capacity_blocks=131072)
+    """BASELINE configs[4] voxel size (extrapolated ray limits) at the full 640x480: ~1e4 blocks, 3e6 distinct voxels and 2.5e7
+    (ray, voxel) updates in the frame."""
+    (la, _, sa), (lb, _, sb) = _both(hip, oracle, method="merged", voxel=0.01, frames=[0], subsample=1, capacity_blocks=131072)
     compare_stats(sa, sb)
     rep = compare_layers(la, lb)
     print(rep, sa[-1])
