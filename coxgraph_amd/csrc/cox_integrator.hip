@@ -3116,6 +3116,15 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     // stage -> stream: 6: one each; 4: H P | M | T R | U; 2: H P M | T R U.  Equal streams are adjacent.
     static const int kMap[3][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}};
     const int* map = kMap[I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    int custom[kNumStages];
+    if (const char* e = std::getenv("COX_STREAM_MAP")) {  // experiments: six digits, stage -> stream, equal streams adjacent (e.g. 012334)
+      bool ok = std::strlen(e) == kNumStages && e[0] == '0';
+      for (int k = 0; ok && k < kNumStages; ++k) {
+        custom[k] = e[k] - '0';
+        ok = custom[k] >= 0 && custom[k] < kNumStages && (k == 0 || custom[k] == custom[k - 1] || custom[k] == custom[k - 1] + 1);
+      }
+      if (ok && method != COX_METHOD_FAST) map = custom;
+    }
     // fast: its front is a chain of short sweeps with host round trips in between, and the record stage of the previous frame
     // running beside it slows every one of them: measured with 16 hardware queues, one stream 2 393 frames/s, two streams
     // 1 898, two streams with the front at high priority 1 952 (with the runtime's default of 4 queues the two streams mostly

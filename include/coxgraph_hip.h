@@ -169,7 +169,7 @@ int cox_integrate_points_ex(cox_integrator_t* integ, const float T_G_C[7], const
  * ORDERING AND LIFETIME of *_dev inputs.  A frame is enqueued on the engine's own non-blocking streams (ray generation and
  * layer update of consecutive frames overlap), which do not order against any stream of the caller.  Either
  *  (a) the caller synchronises the stream that produced xyz_dev / rgba_dev / depth_dev before the call and keeps the
- *      buffers alive and unmodified until cox_integrator_sync (or four more frames have been enqueued), or
+ *      buffers alive and unmodified until cox_integrator_sync, or
  *  (b) the caller registers its producer stream once with cox_integrator_set_input_stream: every later *_dev call then
  *      makes the engine wait for what that stream has enqueued so far, and makes that stream wait until the engine has read
  *      the inputs -- the call behaves as if the read happened on the caller's stream, so a stream-ordered allocator
