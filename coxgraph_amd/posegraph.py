@@ -137,7 +137,7 @@ class PoseGraph:
                 scatter(c.a, c.b, H8[:4, :4], H8[:4, 4:], H8[4:, 4:], g8[:4], g8[4:])
                 cr += ck
             H, g = H_save, g_save
-            if group is not None and world > 1:
+            if group is not None:  # (also with one rank: the same code path a rehearsal on one GPU exercises)
                 import torch
                 import torch.distributed as dist
                 buf = torch.from_numpy(np.concatenate([Hr.reshape(-1), gr, [cr]]))

@@ -165,3 +165,20 @@ def test_registration_waits_for_frames_in_flight(hip, oracle):
     go = Registration(oracle, RegPoints(oracle, pts), lo, 0.0)
     ro, _, _ = go.evaluate(np.zeros(4), np.array([0.02, 0.01, 0.0, 0.01]))
     assert np.array_equal(rh, ro)
+
+
+def test_rccl_paths_on_one_rank():
+    """The RCCL branches of the multi-GPU server path (bench.py --gpus N over backend "nccl": all-gather of device-resident wire
+    arrays, cox_layer_upload_dev / cox_regpoints_create_dev on the receiving side, posegraph.py's packed all-reduce on the
+    device) executed on real hardware -- with one rank, which is what a one-GPU box allows; tests/nccl_single_rank.py."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(here, "nccl_single_rank.py"), str(port)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])  # (RCCL prints a banner first)

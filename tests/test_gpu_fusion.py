@@ -409,6 +409,37 @@ def test_async_device_path_equals_the_synchronous_one(hip, method, sub):
     assert np.array_equal(ja, jb) and np.array_equal(va, vb)
 
 
+@pytest.mark.parametrize("env", [{"COX_STREAMS": "2"}, {"COX_STREAMS": "6"}, {"COX_SUBMIT_THREAD": "0"}, {"COX_STREAMS": "6", "COX_SUBMIT_THREAD": "0"},
+                                 {"COX_GRAPH": "1"}, {"COX_STREAM_MAP": "001234"}])
+@pytest.mark.parametrize("method", ["merged", "simple"])
+def test_pipeline_configurations_give_the_same_layer(hip, monkeypatch, env, method):
+    """The six stages of a frame on 2 / 4 / 6 streams (or any other map), with or without the submission thread, replayed as
+    HIP graphs: 40 frames enqueued back to back (up to six in flight, every buffer set reused several times) must give,
+    bit for bit, the layer the frame-by-frame synchronous path of the default configuration gives."""
+    import torch
+    sub = 3 if method == "merged" else 17
+    frames = [synth.make_frame(t) for t in range(40)]
+    cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
+    a, b = Layer(hip, 0.05, capacity_blocks=16384), Layer(hip, 0.05, capacity_blocks=16384)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ia = Integrator(hip, a, cfg, method)          # the environment is read when an integrator is created
+    for k in env:
+        monkeypatch.delenv(k)
+    ib = Integrator(hip, b, cfg, method)
+    dev = [(T, torch.from_numpy(np.ascontiguousarray(p[::sub])).cuda(), torch.from_numpy(np.ascontiguousarray(c[::sub])).cuda()) for T, p, c, _ in frames]
+    torch.cuda.synchronize()
+    for T, xyz, rgba in dev:
+        ia.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), xyz.shape[0])
+    ia.sync()
+    for T, p, c, _ in frames:
+        ib.integrate_points(T, p[::sub], c[::sub])
+    assert ia.last_stats() == ib.last_stats()
+    ja, va = a.download()
+    jb, vb = b.download()
+    assert np.array_equal(ja, jb) and np.array_equal(va, vb)
+
+
 def test_async_stream_with_changing_sizes_and_a_capacity_growth(hip, oracle):
     """Frames of very different sizes back to back, one of them larger than the integrator's initial capacity (buffers are
     reallocated in the middle of the stream), an empty one in between; checked against the oracle."""
