@@ -285,6 +285,35 @@ def main():
                       "note": ("MergedTsdfIntegrator semantics" if om == "merged" else "FastTsdfIntegrator semantics at integrator_threads=1") +
                               ", bit-exact vs the CPU oracle (DESIGN.md section 5)"}}
 
+        # the fourth integrator the reference configures (method: "projective", tsdf_server_default.yaml:6, tsdf_server_carla.yaml:6):
+        # a gather, not a ray caster; same frames through the yaml files' sensor model (1280 x 960 over 360 degrees)
+        try:
+            nfp = min(nf, 100)
+            pcfg = eng.default_config(sensor_horizontal_resolution=1280, sensor_vertical_resolution=960, sensor_vertical_field_of_view_degrees=360.0,
+                                      **{k: v for k, v in synth.integrator_overrides(args.voxel).items()
+                                         if k in ("default_truncation_distance", "min_ray_length_m", "max_ray_length_m", "use_const_weight", "max_weight")})
+            lp_ = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+            ip_ = Integrator(eng, lp_, pcfg, "projective")
+            for i in range(min(10, args.warmup)):
+                T, xyz, rgba, n = dev_frames[i]
+                ip_.integrate_points_dev(T, xyz.data_ptr(), 0, n)
+            ip_.sync()
+            t0p = time.perf_counter()
+            blocks = 0
+            for i in range(args.warmup, args.warmup + nfp):
+                T, xyz, rgba, n = dev_frames[i]
+                ip_.integrate_points_dev(T, xyz.data_ptr(), 0, n)
+            ip_.sync()
+            dtp = time.perf_counter() - t0p
+            stp = ip_.last_stats()
+            other["projective"] = {"value": nfp / dtp, "unit": "frames/s", "frames": nfp, "ms_per_step": dtp / nfp * 1e3,
+                                   "last_frame": {"n_valid": stp["n_valid"], "n_updates": stp["n_updates"], "n_touched_blocks": stp["n_touched_blocks"]},
+                                   "update_kernel_bytes_last_frame": stp["n_touched_blocks"] * 2 * 49152,
+                                   "note": "ProjectiveTsdfIntegrator semantics (range image + per-voxel gather), one frame in flight, no colours; bit-exact vs "
+                                           "the CPU oracle (tests/test_gpu_projective.py); k_proj_update streams 96 KB per marked block (DESIGN.md section 5d)"}
+        except Exception as e:  # never let the extra block cost the line
+            other["projective"] = {"error": str(e)}
+
     # ---- PCIe-inclusive: what the boundary costs when the caller hands over host buffers -----------------------------------
     pcie = None
     if rank == 0 and world == 1 and args.pcie_frames > 0:
