@@ -32,4 +32,12 @@ for T, xyz in dev[20:]:
 integ.sync()
 dt = time.perf_counter() - t0
 st = integ.last_stats()
+if len(sys.argv) > 3:  # a second pass, one frame at a time: mean marked blocks per frame (for the update kernel's bytes per launch)
+    layer2 = Layer(eng, voxel, capacity_blocks=32768)
+    integ2 = Integrator(eng, layer2, cfg, "projective")
+    tb = []
+    for T, xyz in dev:
+        integ2.integrate_points_dev(T, xyz.data_ptr(), 0, xyz.shape[0])
+        tb.append(integ2.last_stats()["n_touched_blocks"])
+    print(f"marked blocks per frame: mean {np.mean(tb):.1f} (min {min(tb)}, max {max(tb)}) -> k_proj_update streams {np.mean(tb) * 2 * 49152 / 1e6:.2f} MB per launch on average")
 print(f"voxel {voxel}: {(n - 20) / dt:.1f} frames/s, {dt / (n - 20) * 1e3:.3f} ms/frame; last frame: {st}; blocks {layer.stats()[0]}")
