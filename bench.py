@@ -309,7 +309,7 @@ def main():
             other["projective"] = {"value": nfp / dtp, "unit": "frames/s", "frames": nfp, "ms_per_step": dtp / nfp * 1e3,
                                    "last_frame": {"n_valid": stp["n_valid"], "n_updates": stp["n_updates"], "n_touched_blocks": stp["n_touched_blocks"]},
                                    "update_kernel_bytes_last_frame": stp["n_touched_blocks"] * 2 * 49152,
-                                   "note": "ProjectiveTsdfIntegrator semantics (range image + per-voxel gather), one frame in flight, no colours; bit-exact vs "
+                                   "note": "ProjectiveTsdfIntegrator semantics (range image + per-voxel gather), frames queued on one stream, no colours; bit-exact vs "
                                            "the CPU oracle (tests/test_gpu_projective.py); k_proj_update streams 96 KB per marked block (DESIGN.md section 5d)"}
         except Exception as e:  # never let the extra block cost the line
             other["projective"] = {"error": str(e)}

@@ -39,7 +39,10 @@ struct ProjParams {
   u32 n_points, frame_id;
 };
 struct ProjCounters {
-  u32 n_valid, n_rays, n_touched, n_new_blocks, n_updates, err;
+  u32 n_touched, n_new_blocks, err, pad;
+  // one word takes ~88 atomics/us on this chip: the counters that every wave of a large grid adds to are sharded over 64
+  // cache lines (index = workgroup id & 63) and summed by the host.  [s][0] valid points, [s][1] rays cast, [s][2] updates
+  u32 shard[64][16];
 };
 struct ProjLayer {
   u32* voxels;
@@ -116,10 +119,21 @@ __device__ __forceinline__ void block_dda_step(BlockDda& d) {
   d.t_next[2] = (k == 2) ? d.t_next[2] + d.t_step[2] : d.t_next[2];
 }
 
+// Marking is idempotent within a frame, and the 256 neighbouring rays of a workgroup cross the same few dozen blocks: a
+// direct-mapped LDS table of keys this workgroup has already marked answers ~95 % of the steps without a hash probe and a
+// stamp check in global memory (197 -> 60 us at 5 cm).  An entry is written after its block has been marked, so whatever a
+// lane reads there -- old or new -- is a marked block; relaxed LDS accesses, no ordering needed.
+constexpr u32 kSeenSlots = 256;
 __global__ void __launch_bounds__(256) k_proj_points(ProjParams P, const float* __restrict__ xyz, u32* __restrict__ range, ProjLayer L, u32* __restrict__ touched_slots,
                                                      ProjCounters* cnt, u32* layer_err) {
+  __shared__ u64 seen[kSeenSlots];
+  seen[threadIdx.x] = kEmptyKey;
+  __syncthreads();
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 lane = lane_id();
   bool valid = false, casts = false;
+  BlockDda d;
+  d.nsteps = 0;
   if (i < P.n_points) {
     const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     const float distance = sqrtf(dot3(p, p));
@@ -132,44 +146,60 @@ __global__ void __launch_bounds__(256) k_proj_points(ProjParams P, const float* 
           casts = true;
           const float scale = (distance + P.trunc) / distance;
           const F3 far_G = rigid(P.qw, P.qx, P.qy, P.qz, P.tx, P.ty, P.tz, F3{p.x * scale, p.y * scale, p.z * scale});
-          BlockDda d;
           block_dda_setup(d, far_G * P.block_size_inv, F3{P.tx, P.ty, P.tz} * P.block_size_inv);
           if (d.range_error) atomicOr(layer_err, kErrRange);
-          u64 last = kEmptyKey;
-          for (u32 s = 0; s < d.nsteps; ++s) {
-            const u64 bkey = pack_key(d.c[0], d.c[1], d.c[2]);
-            block_dda_step(d);
-            if (bkey == last) continue;
-            last = bkey;
-            bool fresh;
-            const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
-            if (slot == kInvalid) {
-              atomicOr(layer_err, kErrTable);
-              continue;
-            }
-            if (fresh) {
-              const u32 pool = atomicAdd(L.d_nblocks, 1u);
-              if (pool < L.capacity) {
-                L.ht_vals[slot] = pool;
-                L.block_keys[pool] = bkey;
-                atomicAdd(&cnt->n_new_blocks, 1u);
-              } else {
-                atomicSub(L.d_nblocks, 1u);
-                atomicOr(layer_err, kErrPool);
-              }
-            }
-            if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
-                atomicExch(&L.ht_stamp[slot], P.frame_id) != P.frame_id)
-              touched_slots[atomicAdd(&cnt->n_touched, 1u)] = slot;
-          }
         }
       }
     }
   }
+  // the walks of a wave in lockstep (neighbouring lanes are neighbouring pixels: step k of their walks is mostly the same
+  // block): a lane whose lower neighbour holds the same block at the same step leaves it to that lane (which marks it, has
+  // marked it at an earlier step, or leaves it to ITS neighbour in turn)
+  u32 max_steps = d.nsteps;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, static_cast<u32>(__shfl_xor(static_cast<int>(max_steps), off, 64)));
+  u64 last = kEmptyKey;
+  for (u32 s = 0; s < max_steps; ++s) {
+    const bool act = s < d.nsteps;
+    u64 bkey = kEmptyKey;
+    if (act) {
+      bkey = pack_key(d.c[0], d.c[1], d.c[2]);
+      block_dda_step(d);
+    }
+    bool need = act && bkey != last;
+    if (act) last = bkey;
+    const u64 below = __shfl_up(bkey, 1, 64);
+    if (lane > 0 && below == bkey) need = false;
+    if (!need) continue;
+    u64* cell = &seen[static_cast<u32>((bkey * 0x9E3779B97F4A7C15ull) >> 56) & (kSeenSlots - 1u)];
+    if (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == bkey) continue;
+    bool fresh;
+    const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
+    if (slot == kInvalid) {
+      atomicOr(layer_err, kErrTable);
+      continue;
+    }
+    if (fresh) {
+      const u32 pool = atomicAdd(L.d_nblocks, 1u);
+      if (pool < L.capacity) {
+        L.ht_vals[slot] = pool;
+        L.block_keys[pool] = bkey;
+        atomicAdd(&cnt->n_new_blocks, 1u);
+      } else {
+        atomicSub(L.d_nblocks, 1u);
+        atomicOr(layer_err, kErrPool);
+      }
+    }
+    if (__hip_atomic_load(&L.ht_stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id &&
+        atomicExch(&L.ht_stamp[slot], P.frame_id) != P.frame_id)
+      touched_slots[atomicAdd(&cnt->n_touched, 1u)] = slot;
+    __hip_atomic_store(cell, bkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   const u64 mv = __ballot(valid), mc = __ballot(casts);
-  if (lane_id() == 0) {
-    if (mv) atomicAdd(&cnt->n_valid, static_cast<u32>(__popcll(mv)));
-    if (mc) atomicAdd(&cnt->n_rays, static_cast<u32>(__popcll(mc)));
+  if (lane == 0) {
+    u32* sh = cnt->shard[blockIdx.x & 63u];
+    if (mv) atomicAdd(&sh[0], static_cast<u32>(__popcll(mv)));
+    if (mc) atomicAdd(&sh[1], static_cast<u32>(__popcll(mc)));
   }
 }
 
@@ -191,12 +221,17 @@ __device__ __forceinline__ float proj_interpolate(const ProjParams& P, const u32
   return (a * (1.0f - dh) + c * dh) * (1.0f - dw) + (b * (1.0f - dh) + d * dh) * dw;
 }
 
-// one workgroup per marked block; the whole block streams through registers: 48 KB read, 48 KB written, both coalesced
+// one workgroup per EIGHTH of a marked block (two z slabs: 512 voxels, 6 KB of contiguous wire words, two voxels per thread):
+// a frame marks 50-700 blocks, and a voxel is a chain of dependent loads (range pixels, then the voxel) -- one workgroup per
+// block left the chip empty and took 16 such chains per thread (33 us however few blocks); the block still streams through
+// registers, 48 KB read + 48 KB written, coalesced
 __global__ void __launch_bounds__(256) k_proj_update(ProjParams P, const u32* __restrict__ range, ProjLayer L, const u32* __restrict__ touched_slots, ProjCounters* cnt,
                                                      u32* layer_err, u32* __restrict__ h_nblocks) {
+  constexpr u32 kParts = 8, kPartVoxels = kVoxelsPerBlock / kParts;
   const u32 n_touched = cnt->n_touched;
   u32 updates = 0;
-  for (u32 t = blockIdx.x; t < n_touched; t += gridDim.x) {
+  for (u32 t8 = blockIdx.x; t8 < n_touched * kParts; t8 += gridDim.x) {
+    const u32 t = t8 / kParts, part = t8 % kParts;
     const u32 slot = touched_slots[t];
     const u32 pool = L.ht_vals[slot];
     if (pool == kInvalid) {
@@ -207,7 +242,7 @@ __global__ void __launch_bounds__(256) k_proj_update(ProjParams P, const u32* __
     unpack_key(L.ht_keys[slot], &bx, &by, &bz);
     const float ox = static_cast<float>(bx) * P.block_size, oy = static_cast<float>(by) * P.block_size, oz = static_cast<float>(bz) * P.block_size;
     u32* blk = L.voxels + static_cast<size_t>(pool) * kVoxelsPerBlock * kWordsPerVoxel;
-    for (u32 v = threadIdx.x; v < kVoxelsPerBlock; v += 256) {
+    for (u32 v = part * kPartVoxels + threadIdx.x; v < (part + 1) * kPartVoxels; v += 256) {
       const int lx = static_cast<int>(v & 15u), ly = static_cast<int>((v >> 4) & 15u), lz = static_cast<int>(v >> 8);
       const F3 centre{ox + center_coord(lx, P.voxel_size), oy + center_coord(ly, P.voxel_size), oz + center_coord(lz, P.voxel_size)};
       const F3 q = rigid(P.iqw, P.iqx, P.iqy, P.iqz, P.itx, P.ity, P.itz, centre);
@@ -240,7 +275,7 @@ __global__ void __launch_bounds__(256) k_proj_update(ProjParams P, const u32* __
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) updates += __shfl_xor(updates, off, 64);
-  if (lane_id() == 0 && updates) atomicAdd(&cnt->n_updates, updates);
+  if (lane_id() == 0 && updates) atomicAdd(&cnt->shard[blockIdx.x & 63u][2], updates);
   if (blockIdx.x == 0 && threadIdx.x == 0) *h_nblocks = min(*L.d_nblocks, L.capacity);
 }
 
@@ -307,13 +342,16 @@ static int proj_finish(cox_projective* P) {
   COX_HIP(hipStreamSynchronize(P->stream));
   if (P->pending) {
     const ProjCounters& c = *P->h_cnt;
-    P->last.n_valid = c.n_valid;
-    P->last.n_rays = c.n_rays;
-    P->last.n_updates = c.n_updates;
-    P->last.n_touched_voxels = c.n_updates;
+    u64 sums[3] = {0, 0, 0};
+    for (int sh = 0; sh < 64; ++sh)
+      for (int k = 0; k < 3; ++k) sums[k] += c.shard[sh][k];
+    P->last.n_valid = sums[0];
+    P->last.n_rays = sums[1];
+    P->last.n_updates = sums[2];
+    P->last.n_touched_voxels = sums[2];
     P->last.n_touched_blocks = c.n_touched;
     P->last.n_new_blocks = c.n_new_blocks;
-    P->last.max_voxel_updates = c.n_updates ? 1 : 0;
+    P->last.max_voxel_updates = sums[2] ? 1 : 0;
     P->pending = false;
   }
   u32 lerr = 0;
@@ -328,9 +366,12 @@ static int proj_finish(cox_projective* P) {
 int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev, uint64_t n, int deintegrate) {
   cox_layer* L = P->layer;
   hipStream_t s = P->stream;
-  if (P->pending) COX_TRY(proj_finish(P));  // one frame in flight: the counters and the range image are single-buffered
+  // Frames queue up on ONE in-order stream: the range image, the counters and the marked-block list are cleared / rewritten
+  // by the frame itself, so a frame needs no host-side wait for its predecessor; statistics and errors are those of the last
+  // frame / sticky in the layer's error word and are read when somebody asks (sync, last_stats).
   // Layer::allocateBlockPtrByIndex never fails upstream: double the pool once it is half full
   if (L->auto_grow && static_cast<u64>(*L->h_nblocks) * 2 > L->capacity && L->capacity < (1ull << 26)) {
+    COX_HIP(hipStreamSynchronize(s));
     const int st = cox_internal_layer_reserve(L, std::min<u64>(2 * L->capacity, 1ull << 26));
     if (st != COX_OK && st != COX_ERR_OUT_OF_MEMORY) return st;
     if (st == COX_ERR_OUT_OF_MEMORY) L->auto_grow = false;
@@ -343,6 +384,7 @@ int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev
     P->touched_cap = L->ht_cap;
     P->layer_generation = L->generation;
   }
+  if (n == 0 && P->pending) COX_TRY(proj_finish(P));  // an empty frame enqueues nothing: settle the statistics of the one before it first
   P->last = cox_frame_stats{};
   P->last.n_points = n;
   if (n == 0) return COX_OK;
@@ -385,7 +427,7 @@ int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev
   COX_HIP(hipMemsetAsync(P->range, 0x7F, sizeof(u32) * px, s));
   COX_HIP(hipMemsetAsync(P->cnt, 0, sizeof(ProjCounters), s));
   hipLaunchKernelGGL(k_proj_points, dim3(static_cast<u32>((n + 255) / 256)), dim3(256), 0, s, pp, xyz_dev, P->range, PL, P->touched_slots, P->cnt, L->d_err);
-  hipLaunchKernelGGL(k_proj_update, dim3(4096), dim3(256), 0, s, pp, P->range, PL, P->touched_slots, P->cnt, L->d_err, L->h_nblocks);
+  hipLaunchKernelGGL(k_proj_update, dim3(8192), dim3(256), 0, s, pp, P->range, PL, P->touched_slots, P->cnt, L->d_err, L->h_nblocks);
   COX_HIP(hipMemcpyAsync(P->h_cnt, P->cnt, sizeof(ProjCounters), hipMemcpyDeviceToHost, s));
   COX_HIP(hipEventRecord(L->last_write, s));
   L->has_write = true;
@@ -395,7 +437,7 @@ int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev
 }
 
 int cox_proj_integrate_host(cox_projective* P, const float T[7], const float* xyz, uint64_t n, int deintegrate) {
-  if (P->pending) COX_TRY(proj_finish(P));
+  if (P->pending) COX_TRY(proj_finish(P));  // the staging buffer below is single: the frame that used it last is done
   if (n > P->xyz_cap) {
     if (P->own_xyz) (void)hipFree(P->own_xyz);
     P->own_xyz = nullptr;
