@@ -55,6 +55,7 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_depth_points;
   u32 n_sorted_valid;  // valid points as seen in the sorted bundling keys (merged)
   u32 n_piece_slots;   // piece path: sum of the rays' piece bounds = slots of the piece arrays in use
+  u32 n_expanded;      // piece partition: records written by k_piece_expand (what k_apply_block reads)
   // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
   // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
   // [s][0] valid points, [s][1] updates, [s][2] voxels, [s][3] long runs, [s][4] rays
@@ -539,8 +540,8 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
         R.flags[m] = 1u | (clearing ? 2u : 0u);
         R.key[m] = key;
         R.nsteps[m] = d.nsteps;
-        if (piece_axis_cap) {
-          R.pbound[m] = piece_bound(d, piece_axis_cap);
+        if (piece_axis_cap) R.pbound[m] = piece_bound(d, piece_axis_cap);
+        {
           // what compute_sdf derives from the ray alone, with its own operations, once per ray instead of once per step
           const F3 dv = pg - F3{P.tx, P.ty, P.tz};
           typedef float F4 __attribute__((ext_vector_type(4)));
@@ -1006,10 +1007,14 @@ struct PieceArrays {
   u32* key;     // [piece slots]
   u32* start;
   u32* raylen;
+  u64* bkey;    // deferred touch only: the piece's block key (k_piece_touch turns it into the hash slot)
 };
 constexpr u32 kPieceLenBits = 5;
 
-template <u32 kAxisCap>
+// kDefer: the walk touches no block itself (a hash probe and a stamp check are two dependent global round trips per round of
+// 64 steps, and the wave waits for the slowest of its lanes: they were 2/3 of the walk's time at 1 cm); it leaves the block
+// key with every piece (key word = z slab for now) and k_piece_touch does all the touching at once, one thread per piece.
+template <u32 kAxisCap, bool kDefer>
 __global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ touched_slots, uint8_t* __restrict__ lin8,
                                                       PieceArrays PA, u32 rec_cap, u32 piece_cap, Counters* cnt, u32* layer_err) {
   const FrameParams P = *Pp;
@@ -1052,7 +1057,8 @@ __global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restr
         if (lane == 0) prev_key = carry_key;
         const bool bhead = act && bkey != prev_key;
         u32 slot = kInvalid;
-        if (bhead) slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
+        if constexpr (!kDefer)
+          if (bhead) slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
         // every lane takes the slot of the nearest block head at or below it, or the carry of the previous round
         const u64 bheads = __ballot(bhead);
         const u64 upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
@@ -1094,7 +1100,12 @@ __global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restr
           const u32 round_end = min(64u, ns - base);
           const u32 nxt = above ? (lane + static_cast<u32>(__ffsll(static_cast<long long>(above)))) : round_end;
           if (k < bound) {
-            PA.key[poff + k] = (my_slot == kInvalid) ? kInvalid : ((my_slot << 4) | zs);
+            if constexpr (kDefer) {
+              PA.key[poff + k] = zs;
+              PA.bkey[poff + k] = bkey;
+            } else {
+              PA.key[poff + k] = (my_slot == kInvalid) ? kInvalid : ((my_slot << 4) | zs);
+            }
             PA.start[poff + k] = poff + k;
             PA.raylen[poff + k] = (r << kPieceLenBits) | (nxt - lane);
           } else {
@@ -1119,14 +1130,18 @@ __global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restr
           bool head = (s == 0) || zs != last_z || run == 31u;
           if (bkey != last_bkey) {
             last_bkey = bkey;
-            last_slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
+            if constexpr (!kDefer) last_slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
             head = true;
           }
           last_z = zs;
           if (overflow) continue;
           if (head) {
             if (pk < bound) {
-              PA.key[poff + pk] = (last_slot == kInvalid) ? kInvalid : ((last_slot << 4) | zs);
+              if constexpr (kDefer) {
+                PA.key[poff + pk] = zs;
+                PA.bkey[poff + pk] = bkey;
+              } else
+                PA.key[poff + pk] = (last_slot == kInvalid) ? kInvalid : ((last_slot << 4) | zs);
               PA.start[poff + pk] = poff + pk;
               PA.raylen[poff + pk] = (r << kPieceLenBits) | 1u;
             } else {
@@ -1146,6 +1161,166 @@ __global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restr
     // the slots of the bound this ray did not use
     if (!overflow)
       for (u32 i = pk + lane; i < bound; i += 64) PA.key[poff + i] = kInvalid;
+  }
+}
+
+// deferred touch: one thread per piece slot.  Consecutive pieces of a ray mostly stay in one block (z slab changes), so only
+// the first piece of a run of equal block keys touches the block; the others take its slot through the wave.
+// touch_block without the ordinal: insert, give a fresh block its storage, stamp.  The stamp is a plain store (every
+// writer of a frame stores the same value); ordinals come from a scan over the stamps afterwards (k_ord_flags / k_ord_scatter)
+// instead of one atomicAdd per touched block on ONE word (10^4 blocks per frame at 1 cm = 114 us at 88 atomics / us).
+__device__ __forceinline__ u32 touch_block_stamp(const FrameParams& P, const LayerView& L, u64 bkey, Counters* cnt, u32* layer_err) {
+  bool fresh;
+  const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
+  if (slot == kInvalid) {
+    atomicOr(layer_err, kErrTable);
+    return kInvalid;
+  }
+  if (fresh) {
+    const u32 pool = atomicAdd(L.d_nblocks, 1u);
+    if (pool < L.capacity) {
+      L.ht_vals[slot] = pool;
+      L.block_keys[pool] = bkey;
+      atomicAdd(&cnt->n_new_blocks, 1u);
+    } else {
+      atomicSub(L.d_nblocks, 1u);
+      atomicOr(layer_err, kErrPool);
+    }
+  }
+  if (L.ht_stamp[slot] != P.frame_id) L.ht_stamp[slot] = P.frame_id;
+  return slot;
+}
+// ordinals of the blocks stamped this frame: flags over the hash slots -> exclusive scan (in ht_ord) -> dense slot list
+__global__ void __launch_bounds__(256) k_ord_flags(const FrameParams* __restrict__ Pp, LayerView L) {
+  const u32 frame = Pp->frame_id, n = L.ht_mask + 1u;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) L.ht_ord[i] = (L.ht_stamp[i] == frame) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_ord_scatter(const FrameParams* __restrict__ Pp, LayerView L, u32* __restrict__ touched_slots) {
+  const u32 frame = Pp->frame_id, n = L.ht_mask + 1u;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (L.ht_stamp[i] == frame) touched_slots[L.ht_ord[i]] = i;
+}
+constexpr u32 kPieceSeen = 512;
+__global__ void __launch_bounds__(256) k_piece_touch(const FrameParams* __restrict__ Pp, LayerView L, PieceArrays PA, u32 rec_cap, u32 piece_cap, u32* __restrict__ touched_slots,
+                                                     Counters* cnt, u32* layer_err) {
+  const FrameParams P = *Pp;
+  // The blocks around the sensor are crossed by every ray: tens of thousands of lanes probing the same few hash lines
+  // serialise in L2 (230 us at 1 cm).  A per-wave table block key -> hash slot answers the repeats from LDS.  Two words per
+  // entry, so an entry is (1) invalidated, (2) given its key, (3) given its slot by the lane whose key is found there on
+  // reading back; lanes of one wave execute these steps in order, which is why the table is not shared between waves.
+  __shared__ u64 ckey[4][kPieceSeen];
+  __shared__ u32 cslot[4][kPieceSeen];
+  for (u32 q = threadIdx.x; q < 4 * kPieceSeen; q += 256) {
+    (&ckey[0][0])[q] = kEmptyKey;
+    (&cslot[0][0])[q] = kInvalid;
+  }
+  __syncthreads();
+  const u32 n = cnt->n_piece_slots;
+  if (cnt->n_records > rec_cap || n > piece_cap) return;  // frame dropped (k_piece_keys reports it)
+  const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+  const u32 n_round = (n + 63u) & ~63u;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {  // whole waves: shuffles below
+    const u32 k = (i < n) ? PA.key[i] : kInvalid;
+    const bool valid = k != kInvalid;
+    const u64 bkey = valid ? PA.bkey[i] : kEmptyKey;
+    const u64 prev = __shfl_up(bkey, 1, 64);
+    const bool head = valid && (lane == 0 || prev != bkey);
+    u32 slot = kInvalid;
+    const u32 ci = static_cast<u32>((bkey * 0x9E3779B97F4A7C15ull) >> 40) & (kPieceSeen - 1u);
+    bool miss = head;
+    if (head && ckey[wv][ci] == bkey) {
+      slot = cslot[wv][ci];
+      miss = slot == kInvalid;
+    }
+    if (miss) slot = touch_block_stamp(P, L, bkey, cnt, layer_err);
+    if (__ballot(miss)) {  // (wave-uniform) publish what was looked up
+      const bool pub = miss && slot != kInvalid;
+      if (pub) cslot[wv][ci] = kInvalid;
+      wave_lds_handover();
+      if (pub) ckey[wv][ci] = bkey;
+      wave_lds_handover();
+      if (pub && ckey[wv][ci] == bkey) cslot[wv][ci] = slot;
+      wave_lds_handover();
+    }
+    const u64 heads = __ballot(head);
+    const u64 below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int src = below ? (63 - __clzll(static_cast<long long>(below))) : 0;
+    const u32 my_slot = static_cast<u32>(__shfl(static_cast<int>(slot), src, 64));  // (a valid lane always has a head at or below it)
+    if (valid) PA.key[i] = (my_slot == kInvalid) ? kInvalid : ((my_slot << 4) | k);
+  }
+}
+
+// ---- piece partition: pieces sorted by tile, then EXPANDED into the (voxel id, ray) records k_apply_block reads -------------
+// The record partition moves 16 B per record and pass; the pieces are 6-10 x fewer and 12 B each.  After the piece sort a
+// scan of the piece lengths gives every piece its place in the record array, and the expansion writes the records of 256
+// pieces at a time, lane = record (fully coalesced stores), finding each record's piece by binary search in LDS.
+__global__ void __launch_bounds__(256) k_piece_lens(const u32* __restrict__ key0, const u32* __restrict__ key1, const u32* __restrict__ rl0, const u32* __restrict__ rl1,
+                                                    const SortInfo* __restrict__ info, u32* __restrict__ len, const Counters* cnt) {
+  const u32 par = info->parity & 1u;
+  const u32* __restrict__ key = par ? key1 : key0;
+  const u32* __restrict__ rl = par ? rl1 : rl0;
+  const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) len[i] = (key[i] != kInvalid) ? (rl[i] & ((1u << kPieceLenBits) - 1u)) : 0u;
+}
+// record range of every tile from the sorted pieces and their scan (5-10 x fewer elements than the records k_block_starts reads)
+__global__ void __launch_bounds__(256) k_piece_tile_ranges(const u32* __restrict__ key0, const u32* __restrict__ key1, const SortInfo* __restrict__ info,
+                                                           const u32* __restrict__ len, const u32* __restrict__ dest, u32* __restrict__ tile_beg, u32* __restrict__ tile_end,
+                                                           const Counters* cnt) {
+  const u32* __restrict__ key = (info->parity & 1u) ? key1 : key0;
+  const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 t = key[i];
+    if (t == kInvalid) continue;  // (invalid keys sort last)
+    if (i == 0 || key[i - 1] != t) tile_beg[t] = dest[i];
+    if (i + 1 == n || key[i + 1] != t) tile_end[t] = dest[i] + len[i];
+  }
+}
+__global__ void __launch_bounds__(256) k_piece_expand(const u32* __restrict__ key0, const u32* __restrict__ key1, const u32* __restrict__ st0, const u32* __restrict__ st1,
+                                                      const u32* __restrict__ rl0, const u32* __restrict__ rl1, const SortInfo* __restrict__ info,
+                                                      const u32* __restrict__ dest, const uint8_t* __restrict__ lin8, u32* __restrict__ rec_key, u32* __restrict__ rec_ray,
+                                                      const Counters* cnt) {
+  __shared__ u32 s_off[257], s_key[256], s_ray[256], s_slot[256], lds[4];
+  const u32 par = info->parity & 1u;
+  const u32* __restrict__ key = par ? key1 : key0;
+  const u32* __restrict__ start = par ? st1 : st0;
+  const u32* __restrict__ rl = par ? rl1 : rl0;
+  const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
+  const u32 n_chunks = (n + 255u) / 256u;
+  for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const u32 i = c * 256u + threadIdx.x;
+    u32 k = kInvalid, len = 0;
+    if (i < n) {
+      k = key[i];
+      if (k != kInvalid) {
+        const u32 v = rl[i];
+        len = v & ((1u << kPieceLenBits) - 1u);
+        s_ray[threadIdx.x] = v >> kPieceLenBits;
+        s_slot[threadIdx.x] = start[i];
+        s_key[threadIdx.x] = k << 8;  // tile id (ordinal << 4 | z slab) -> voxel id without its low byte
+      }
+    }
+    u32 tot;
+    const u32 off = block_exclusive_scan<4>(len, &tot, lds);
+    s_off[threadIdx.x] = off;
+    if (threadIdx.x == 0) s_off[256] = tot;
+    __syncthreads();
+    const u32 base = dest[c * 256u];  // records before this chunk (exclusive scan of the lengths)
+    for (u32 t = threadIdx.x; t < tot; t += 256) {
+      u32 lo = 0, hi = 256;  // the piece p with s_off[p] <= t < s_off[p + 1] (pieces of length 0 are never hit)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const u32 mid = (lo + hi) >> 1;
+        if (s_off[mid] <= t)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      // among pieces with the same offset (empty ones) lo is the last: the one that holds t
+      const u32 j = t - s_off[lo];
+      rec_key[base + t] = s_key[lo] | lin8[static_cast<size_t>(s_slot[lo]) * 32u + j];
+      rec_ray[base + t] = s_ray[lo];
+    }
+    __syncthreads();
   }
 }
 
@@ -1619,7 +1794,43 @@ __device__ __forceinline__ void tile_flush(const FrameParams& P, u32* blk, u32* 
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
+// compute_sdf with the ray's part (dv = point_G - origin, dist = |dv|) taken from RayArrays::q: the same operations on the same values
+__device__ __forceinline__ float step_sdf(const FrameParams& P, F3 dv, float dist, int gx, int gy, int gz) {
+  const F3 origin{P.tx, P.ty, P.tz};
+  const F3 c{center_coord(gx, P.voxel_size), center_coord(gy, P.voxel_size), center_coord(gz, P.voxel_size)};
+  const F3 v = c - origin;
+  const float proj = dot3(v, dv) / dist;
+  return dist - proj;
+}
+
+// what a record needs from its ray.  kQ (merged): one 32-B line written by the merge -- point_G - origin, its length, the
+// weight -- instead of four 4-B gathers from four arrays; the ray gathers were a quarter of this kernel at 1 cm with one
+// frame in flight and 40 % of it beside the other stages (ablation: DESIGN.md section 6)
+struct RayOfRecord {
+  F3 a;      // kQ: point_G - origin; else point_G
+  float dist, w;
+};
+template <bool kQ>
+__device__ __forceinline__ RayOfRecord ray_of_record(const RayArrays& R, u32 r) {
+  if constexpr (kQ) {
+    typedef float F4 __attribute__((ext_vector_type(4)));
+    const F4* q = reinterpret_cast<const F4*>(R.q + static_cast<size_t>(r) * 8u);
+    const F4 q0 = q[0];
+    return RayOfRecord{F3{q0.x, q0.y, q0.z}, q0.w, q[1].x};
+  } else {
+    return RayOfRecord{F3{R.px[r], R.py[r], R.pz[r]}, 0.0f, R.w[r]};
+  }
+}
+template <bool kQ>
+__device__ __forceinline__ float sdf_of_record(const FrameParams& P, const RayOfRecord& y, int gx, int gy, int gz) {
+  if constexpr (kQ)
+    return step_sdf(P, y.a, y.dist, gx, gy, gz);
+  else
+    return compute_sdf(P, y.a, gx, gy, gz);
+}
+
+template <bool kQ>
+__global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
                                                      u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
   const FrameParams P = *Pp;
   __shared__ u32 blk[kTileVox * kWordsPerVoxel];
@@ -1669,15 +1880,14 @@ __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restri
       const bool has1 = i1 < end;
       const u32 k0 = rec_key[i0], r0 = rec_ray[i0];
       const u32 k1 = has1 ? rec_key[i1] : 0u, r1 = has1 ? rec_ray[i1] : r0;
-      const F3 pg0{R.px[r0], R.py[r0], R.pz[r0]}, pg1{R.px[r1], R.py[r1], R.pz[r1]};
-      const float rw0 = R.w[r0], rw1 = R.w[r1];
+      const RayOfRecord y0 = ray_of_record<kQ>(R, r0), y1 = ray_of_record<kQ>(R, r1);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 1 && !has1) break;
         const u32 lin = (u ? k1 : k0) & (kTileVox - 1u);
-        const F3 pg = u ? pg1 : pg0;
-        const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
-        const float uw = update_weight(P, sdf, u ? rw1 : rw0);
+        const RayOfRecord& y = u ? y1 : y0;
+        const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+        const float uw = update_weight(P, sdf, y.w);
         bool fold = foldable_update(P, sdf, uw);
         if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
         atomicAdd(&acc_cnt[lin], 1u);
@@ -1747,9 +1957,9 @@ __global__ void __launch_bounds__(kBT) k_apply_block(const FrameParams* __restri
         for (u32 w = 0; w < wave; ++w) pos += wsum[w];
         if (keep) {
           const u32 r = rec_ray[i];
-          const F3 pg{R.px[r], R.py[r], R.pz[r]};
-          const float sdf = compute_sdf(P, pg, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
-          const float uw = update_weight(P, sdf, R.w[r]);
+          const RayOfRecord y = ray_of_record<kQ>(R, r);
+          const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+          const float uw = update_weight(P, sdf, y.w);
           b_lin[pos] = static_cast<unsigned short>(lin | (foldable_update(P, sdf, uw) ? 0x8000u : 0u));
           b_sdf[pos] = sdf;
           b_uw[pos] = uw;
@@ -1796,15 +2006,6 @@ struct PieceView {
   const SortInfo* info;
 };
 typedef u32 U32x4 __attribute__((ext_vector_type(4)));
-
-// compute_sdf with the ray's part (dv = point_G - origin, dist = |dv|) taken from RayArrays::q: the same operations on the same values
-__device__ __forceinline__ float step_sdf(const FrameParams& P, F3 dv, float dist, int gx, int gy, int gz) {
-  const F3 origin{P.tx, P.ty, P.tz};
-  const F3 c{center_coord(gx, P.voxel_size), center_coord(gy, P.voxel_size), center_coord(gz, P.voxel_size)};
-  const F3 v = c - origin;
-  const float proj = dot3(v, dv) / dist;
-  return dist - proj;
-}
 
 // f(j, lin) for every step j < len of this lane's piece, lanes in lockstep (j is wave-uniform; every lane of the wave must call)
 template <typename F>
@@ -2131,6 +2332,8 @@ struct RecordSet {  // lives B1 .. B2
   // piece path (merged): the walk as bytes + the (ray, tile) pieces, ping-pong for their sort; the record arrays stay unallocated
   uint8_t* lin8 = nullptr;
   u32 *pkey[2] = {nullptr, nullptr}, *pstart[2] = {nullptr, nullptr}, *prl[2] = {nullptr, nullptr};
+  u64* pbkey = nullptr;                   // piece partition: block key of every piece until k_piece_touch has run
+  u32 *plen = nullptr, *pdest = nullptr;  // piece partition: lengths of the sorted pieces, their exclusive scan
   u32* touched_slots = nullptr;  // [layer ht_cap]
   int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
   u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap * 16] record range of every tile (block apply); zero between frames
@@ -2239,6 +2442,9 @@ struct cox_integrator {
   FILE* timeline = nullptr;
   u32 grid_apply = 8192, grid_merge = 4096, grid_touch = 2048;  // grid-stride kernels: any size is correct (COX_GRID_* for experiments)
   bool piece_path = false;      // COX_APPLY=pieces (merged without anti-grazing): pieces instead of records (k_touch_pieces / k_apply_pieces)
+  bool piece_sort = false;      // pieces are walked and sorted, then expanded into records for k_apply_block (fine voxels; COX_PARTITION=pieces|records)
+  ScanWorkspace scanws_p;       // scan of the piece lengths
+  ScanWorkspace scanws_h;       // piece partition: scan over the layer's hash slots (ordinals of the stamped blocks)
   u32 piece_cap = 0;
   bool block_apply = true;      // records partitioned by block + k_apply_block; COX_APPLY=records selects the per-record kernels (full sort)
   // ordering against the caller's stream (cox_integrator_set_input_stream): the first stage waits for what the producer has
@@ -2381,12 +2587,19 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   const u64 per_ray = static_cast<u64>(I->steps_max + 63) / 64 + (planes + 2) + 2 * ((planes + 2) / 16 + 1) + 4;
   const u32 piece_cap = static_cast<u32>(std::min<u64>(rcap, static_cast<u64>(cap) * per_ray));
   for (RecordSet& S : I->rs) {
-    if (I->piece_path) {
+    if (I->piece_path || I->piece_sort) {
       COX_TRY(dev_realloc(&S.lin8, static_cast<size_t>(piece_cap) * 32));
       for (int k = 0; k < 2; ++k) {
         COX_TRY(dev_realloc(&S.pkey[k], piece_cap));
         COX_TRY(dev_realloc(&S.pstart[k], piece_cap));
         COX_TRY(dev_realloc(&S.prl[k], piece_cap));
+      }
+      if (I->piece_sort) {
+        COX_TRY(dev_realloc(&S.pbkey, piece_cap));
+        COX_TRY(dev_realloc(&S.plen, piece_cap));
+        COX_TRY(dev_realloc(&S.pdest, piece_cap));
+        COX_TRY(dev_realloc(&S.rec_key[0], rcap));
+        COX_TRY(dev_realloc(&S.rec_ray[0], rcap));
       }
       continue;
     }
@@ -2399,7 +2612,8 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&S.piece_wsum, static_cast<size_t>(wave_cap) * 2));
   }
   I->piece_cap = piece_cap;
-  COX_TRY(alloc_sort_ws(&I->sort_rec, I->piece_path ? piece_cap : rcap));
+  COX_TRY(alloc_sort_ws(&I->sort_rec, (I->piece_path || I->piece_sort) ? piece_cap : rcap));
+  if (I->piece_sort) COX_TRY(dev_realloc(&I->scanws_p.block_sums, scan_num_blocks(piece_cap) + 2));
   if (I->method == COX_METHOD_FAST) {
     COX_TRY(alloc_sort_ws(&I->sort_vis, rcap));
     FastState& X = I->fast;
@@ -2573,7 +2787,7 @@ static int stage_merge(const StageCtx& c, hipStream_t s) {
     hipLaunchKernelGGL(k_bundle_starts, gt, dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
     TimedRegion t(I, COX_KC_MERGE, s);
     hipLaunchKernelGGL(k_bundle_merge, dim3(I->grid_merge), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt,
-                       I->piece_path ? (I->small_axis_cap ? kAxisCapSmall : kAxisCapLarge) : 0u);
+                       (I->piece_path || I->piece_sort) ? (I->small_axis_cap ? kAxisCapSmall : kAxisCapLarge) : 0u);
   } else {
     hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, F.d_params, F.rays, F.cnt);
   }
@@ -2642,18 +2856,36 @@ static int stage_touch(const StageCtx& c, hipStream_t s) {
   const LayerView L = layer_view(I->layer);
   const u32 fh_mask = I->fh_cap - 1;
   const bool merged = I->method == COX_METHOD_MERGED;
-  if (I->piece_path) {
-    const PieceArrays PA{S.pkey[0], S.pstart[0], S.prl[0]};
+  if (I->piece_path || I->piece_sort) {
+    const PieceArrays PA{S.pkey[0], S.pstart[0], S.prl[0], S.pbkey};
     {
       TimedRegion t_walk(I, COX_KC_TOUCH_EMIT, s);
-      hipLaunchKernelGGL(k_scan_small2, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_records, F.rays.pbound, F.rays.piece_off,
-                         &F.cnt->n_piece_slots, &F.cnt->n_ray_slots, I->pcap);
-      if (I->small_axis_cap)
-        hipLaunchKernelGGL(k_touch_pieces<kAxisCapSmall>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.lin8, PA, I->rcap, I->piece_cap,
-                           F.cnt, I->layer->d_err);
-      else
-        hipLaunchKernelGGL(k_touch_pieces<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.lin8, PA, I->rcap, I->piece_cap,
-                           F.cnt, I->layer->d_err);
+      if (I->small_axis_cap) {  // a few thousand bundles: one launch, one workgroup
+        hipLaunchKernelGGL(k_scan_small2, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_records, F.rays.pbound, F.rays.piece_off,
+                           &F.cnt->n_piece_slots, &F.cnt->n_ray_slots, I->pcap);
+      } else {  // fine voxels, 10^4-10^5 bundles: the three-kernel scans (the one-workgroup scan took 75 us at 1 cm)
+        exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_records, I->scanws_b, s);
+        exclusive_scan_u32(F.rays.pbound, F.rays.piece_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_piece_slots, I->scanws_b, s);
+      }
+#define COX_LAUNCH_WALK(CAP, DEFER)                                                                                                                       \
+  hipLaunchKernelGGL((k_touch_pieces<CAP, DEFER>), dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.lin8, PA, I->rcap, I->piece_cap, \
+                     F.cnt, I->layer->d_err)
+      if (I->piece_sort) {
+        if (I->small_axis_cap)
+          COX_LAUNCH_WALK(kAxisCapSmall, true);
+        else
+          COX_LAUNCH_WALK(kAxisCapLarge, true);
+        hipLaunchKernelGGL(k_piece_touch, dim3(2048), dim3(256), 0, s, F.d_params, L, PA, I->rcap, I->piece_cap, S.touched_slots, F.cnt, I->layer->d_err);
+        const u32 ht_cap = I->layer->ht_cap;
+        hipLaunchKernelGGL(k_ord_flags, grid_for(ht_cap, 256, 4096), dim3(256), 0, s, F.d_params, L);
+        exclusive_scan_u32(L.ht_ord, L.ht_ord, nullptr, ht_cap, ht_cap, &F.cnt->n_touched, I->scanws_h, s);
+        hipLaunchKernelGGL(k_ord_scatter, grid_for(ht_cap, 256, 4096), dim3(256), 0, s, F.d_params, L, S.touched_slots);
+      } else if (I->small_axis_cap) {
+        COX_LAUNCH_WALK(kAxisCapSmall, false);
+      } else {
+        COX_LAUNCH_WALK(kAxisCapLarge, false);
+      }
+#undef COX_LAUNCH_WALK
       hipLaunchKernelGGL(k_piece_keys, dim3(1024), dim3(256), 0, s, L, S.pkey[0], I->rcap, I->piece_cap, F.cnt, S.sort_info, S.touched_slots, S.ord_info);
     }
     return COX_OK;
@@ -2685,10 +2917,18 @@ static int stage_record_sort(const StageCtx& c, hipStream_t s) {
   FrameSet& F = *c.F;
   RecordSet& S = *c.S;
   TimedRegion t_sort(I, COX_KC_RECORD_SORT, s);
-  if (I->piece_path) {
+  if (I->piece_path || I->piece_sort) {
     // 4 + ceil(log2(touched blocks + 1)) key bits: one pass up to 255 touched blocks, two beyond
     (void)radix_sort_pairs<12>(S.pkey[0], S.pstart[0], S.pkey[1], S.pstart[1], &F.cnt->n_piece_slots, I->piece_cap, std::min<u32>(I->piece_cap, 1u << 21), 0,
                                true, 2, I->sort_rec, S.sort_info, s, S.prl[0], S.prl[1]);
+    if (I->piece_sort) {  // sorted pieces -> records in tile order
+      const u32 hint = std::min<u32>(I->piece_cap, 1u << 22);
+      hipLaunchKernelGGL(k_piece_lens, grid_for(hint, 256, 8192), dim3(256), 0, s, S.pkey[0], S.pkey[1], S.prl[0], S.prl[1], S.sort_info, S.plen, F.cnt);
+      exclusive_scan_u32(S.plen, S.pdest, &F.cnt->n_piece_slots, I->piece_cap, hint, &F.cnt->n_expanded, I->scanws_p, s);
+      hipLaunchKernelGGL(k_piece_expand, dim3(8192), dim3(256), 0, s, S.pkey[0], S.pkey[1], S.pstart[0], S.pstart[1], S.prl[0], S.prl[1], S.sort_info, S.pdest,
+                         S.lin8, S.rec_key[0], S.rec_ray[0], F.cnt);
+      hipLaunchKernelGGL(k_piece_tile_ranges, grid_for(hint, 256, 8192), dim3(256), 0, s, S.pkey[0], S.pkey[1], S.sort_info, S.plen, S.pdest, S.blk_beg, S.blk_end, F.cnt);
+    }
     return COX_OK;
   }
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
@@ -2706,6 +2946,7 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
   RecordSet& S = *c.S;
   const LayerView L = layer_view(I->layer);
   RecordView V{{S.rec_key[0], S.rec_key[1]}, {S.rec_ray[0], S.rec_ray[1]}, S.sort_info, &F.cnt->n_records};
+  if (I->piece_sort) V = RecordView{{S.rec_key[0], S.rec_key[0]}, {S.rec_ray[0], S.rec_ray[0]}, S.sort_info, &F.cnt->n_expanded};  // one buffer: the parity is the piece sort's
   TimedRegion t(I, COX_KC_APPLY, s);
   if (I->piece_path) {
     const RecordView KV{{S.pkey[0], S.pkey[1]}, {nullptr, nullptr}, S.sort_info, &F.cnt->n_piece_slots};
@@ -2716,9 +2957,14 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
     return COX_OK;
   }
   if (I->block_apply) {
-    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, kTileShift);
-    hipLaunchKernelGGL(k_apply_block, dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
-                       I->layer->h_nblocks);
+    if (!I->piece_sort)  // (piece partition: the ranges come with the expansion, k_piece_tile_ranges)
+      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, kTileShift);
+    if (I->method == COX_METHOD_MERGED)  // the merge leaves RayArrays::q
+      hipLaunchKernelGGL(k_apply_block<true>, dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
+                         I->layer->h_nblocks);
+    else
+      hipLaunchKernelGGL(k_apply_block<false>, dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
+                         I->layer->h_nblocks);
     return COX_OK;
   }
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
@@ -2899,6 +3145,7 @@ static int follow_layer(cox_integrator* I) {
       COX_HIP(hipMemset(S.blk_end, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
       COX_HIP(hipDeviceSynchronize());
     }
+    if (I->piece_sort) COX_TRY(dev_realloc(&I->scanws_h.block_sums, scan_num_blocks(Lh->ht_cap) + 2));
     I->layer_generation = Lh->generation;
   }
   return COX_OK;
@@ -3128,6 +3375,15 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   if (const char* e = std::getenv("COX_GRID_MERGE")) I->grid_merge = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("COX_GRID_TOUCH")) I->grid_touch = std::max(1, std::atoi(e));
   I->piece_path = method == COX_METHOD_MERGED && !cfg->enable_anti_grazing && std::getenv("COX_APPLY") && std::string(std::getenv("COX_APPLY")) == "pieces";
+  // COX_PARTITION=pieces: the walk leaves pieces, the pieces are sorted by tile and expanded into the records of the default
+  // tile apply (k_touch_pieces<deferred touch> / k_piece_touch / k_piece_expand); =records: the record partition
+  // Default: pieces where rays are long in voxels (the large-LDS walk: 2 cm and finer with the reference's ray lengths) --
+  // 1 cm 513 -> 699 frames/s, 2 cm 2 071 -> 2 159; records otherwise (5 cm: 7 129 vs 5 323, the extra launches cost more than
+  // the smaller sort saves at 4 * 10^5 records per frame).
+  if (method == COX_METHOD_MERGED && !cfg->enable_anti_grazing && !I->piece_path && I->block_apply) {
+    I->piece_sort = (max_steps_per_ray(I) - 1) / 3 + 2 > kAxisCapSmall;
+    if (const char* e = std::getenv("COX_PARTITION")) I->piece_sort = std::string(e) == "pieces";
+  }
   int st = COX_OK;
   auto ev = [&](hipEvent_t* e) {
     if (st == COX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
@@ -3205,6 +3461,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
       st = COX_ERR_NO_DEVICE;
     info(&S.sort_info);
   }
+  if (st == COX_OK && I->piece_sort) st = dev_realloc(&I->scanws_h.block_sums, scan_num_blocks(layer->ht_cap) + 2);
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_ring), sizeof(Counters) * kStatRing, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_params), sizeof(FrameParams) * kFrameSets, hipHostMallocDefault) != hipSuccess)
@@ -3282,7 +3539,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   if (I->timeline) fclose(I->timeline);
   std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
-                             I->scanws_f.block_sums};
+                             I->scanws_f.block_sums, I->scanws_p.block_sums, I->scanws_h.block_sums};
   {
     FastState& X = I->fast;
     for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
@@ -3316,7 +3573,8 @@ void cox_integrator_destroy(cox_integrator_t* I) {
                     static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots), static_cast<void*>(S.ord_info),
                     static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end), static_cast<void*>(S.lin8), static_cast<void*>(S.pkey[0]),
                     static_cast<void*>(S.pkey[1]), static_cast<void*>(S.pstart[0]), static_cast<void*>(S.pstart[1]), static_cast<void*>(S.prl[0]),
-                    static_cast<void*>(S.prl[1]), static_cast<void*>(S.sort_info)})
+                    static_cast<void*>(S.prl[1]), static_cast<void*>(S.pbkey), static_cast<void*>(S.plen), static_cast<void*>(S.pdest),
+                    static_cast<void*>(S.sort_info)})
       ptrs.push_back(p);
     events.push_back(S.done);
   }

@@ -161,7 +161,9 @@ template <int RB>
 __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ k0, const u32* __restrict__ k1, const u32* __restrict__ d_n, u32 n_max,
                                                         int pass, const SortInfo* __restrict__ info, int host_bits,
                                                         u32* __restrict__ counts /*[n_tiles][2^bits]*/, u32 tiles_cap, u32* __restrict__ totals /*[2^bits]*/) {
-  __shared__ u32 h[1u << RB];  // RB = widest digit; this pass sorts on `bits` <= RB bits at `shift`
+  __shared__ u32 h[1u << RB];    // RB = widest digit; this pass sorts on `bits` <= RB bits at `shift`
+  __shared__ u32 acc[1u << RB];  // this workgroup's share of the digit totals: ONE atomic per digit and workgroup, not per tile
+                                 // (12 000 tiles x 512 digits of atomics were most of this kernel at 2.5 * 10^7 records)
   int shift;
   u32 bits;
   if (!rs_pass_digits<RB>(host_bits >= 0 ? static_cast<u32>(host_bits) : info->nbits, pass, &shift, &bits)) return;
@@ -171,6 +173,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ 
   const u32 n = d_n ? min(*d_n, n_max) : n_max;
   const u32 tile_elems = static_cast<u32>(kRsTile) << rs_tile_shift(n);
   const u32 n_tiles = (n + tile_elems - 1) / tile_elems;
+  for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) acc[d] = 0;  // (digit d is always handled by the same thread)
   for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) h[d] = 0;
     __syncthreads();
@@ -180,10 +183,12 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const u32* __restrict__ 
     for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads) {
       const u32 c = h[d];
       counts[static_cast<size_t>(tile) * kDigits + d] = c;  // tile-major: coalesced here and in the scatter kernel
-      if (c) atomicAdd(&totals[d], c);
+      acc[d] += c;
     }
     __syncthreads();
   }
+  for (u32 d = threadIdx.x; d < kDigits; d += kRsThreads)
+    if (acc[d]) atomicAdd(&totals[d], acc[d]);
 }
 
 // counts[tile][digit] -> position of the first element of (tile, digit) in the sorted output =
@@ -362,7 +367,7 @@ static inline int radix_sort_pairs(u32* k0, u32* v0, u32* k1, u32* v1, const u32
   const int hb = bits_on_device ? -1 : host_bits;
   for (int p = 0; p < passes; ++p) {
     u32* totals = ws.totals + (static_cast<size_t>(p) << kRsMaxDigitBits);
-    hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
+    hipLaunchKernelGGL(k_rs_hist<RB>, dim3(grid < 1024 ? grid : 1024), dim3(kRsThreads), 0, s, k0, k1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
     hipLaunchKernelGGL(k_rs_offsets<RB>, dim3((1u << RB) / 64u), dim3(kRsOffThreads), 0, s, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
     hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(grid), dim3(kRsThreads), 0, s, k0, v0, k1, v1, x0, x1, d_n, n_max, p, info, hb, ws.counts, ws.tiles_cap, totals);
   }
