@@ -327,7 +327,9 @@ __global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collis
       any |= (stop != reach_in[r]);
     }
   }
-  if (any) atomicOr(changed, 1u);
+  // one word for the whole grid: only the first few waves that changed something write it (a same-address atomic per wave of the
+  // first sweep, where every ray changes, was 50 us of serialised traffic)
+  if (any && __hip_atomic_load(changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(changed, 1u);
 }
 // after the last sweep: the table keeps the hash of the last performed operation on each slot
 __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32* __restrict__ reach, const u32* __restrict__ eloc, const u32* __restrict__ tmax,
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256) k_fast_grow_caps(const u32* __restrict__ 
       any = true;
     }
   }
-  if (__ballot(any) && lane_id() == 0) atomicOr(grew, 1u);
+  if (__ballot(any) && lane_id() == 0 && __hip_atomic_load(grew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(grew, 1u);
 }
 // hand the rays over to the record pipeline: a ray emits its first reach[r] voxels
 __global__ void __launch_bounds__(256) k_fast_finish(RayArrays R, const u32* __restrict__ reach, Counters* cnt) {
