@@ -77,7 +77,7 @@ def pmc(path, name):
     apply dispatch (k_apply_block by default: exactly one per frame, the last kernel of a frame in --serial mode)."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_apply_block", "k_apply_pieces", "k_apply_long"))]
+    ends = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"].split("(")[0] for k in ("k_apply_block", "k_apply_pieces", "k_apply_long"))]
     assert len(ends) >= STEADY + 1, len(ends)
     lo, hi = ends[-STEADY - 1] + 1, ends[-1] + 1
     acc, cnt, order = collections.defaultdict(float), collections.defaultdict(int), []
