@@ -635,9 +635,9 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
     const bool overflow = cnt->n_records > rec_cap;
-    sort_info->nbits = overflow ? 0u : (by_block ? bits - 8u : bits);  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : bits - static_cast<u32>(by_block);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = by_block ? 8u : 0u;  // block apply: a stable partition by tile (block ordinal, z slab) is all the global order it needs
+    sort_info->base = static_cast<u32>(by_block);  // block apply (by_block = its tile shift): a stable partition by tile is all the global order it needs
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (cnt->n_records > rec_cap) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -913,9 +913,9 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : (by_block ? bits - 8u : bits);  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : bits - static_cast<u32>(by_block);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = by_block ? 8u : 0u;
+    sort_info->base = static_cast<u32>(by_block);
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (overflow) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -1265,14 +1265,15 @@ __global__ void __launch_bounds__(256) k_piece_lens(const u32* __restrict__ key0
 // record range of every tile from the sorted pieces and their scan (5-10 x fewer elements than the records k_block_starts reads)
 __global__ void __launch_bounds__(256) k_piece_tile_ranges(const u32* __restrict__ key0, const u32* __restrict__ key1, const SortInfo* __restrict__ info,
                                                            const u32* __restrict__ len, const u32* __restrict__ dest, u32* __restrict__ tile_beg, u32* __restrict__ tile_end,
-                                                           const Counters* cnt) {
+                                                           const Counters* cnt, u32 slab_shift) {
   const u32* __restrict__ key = (info->parity & 1u) ? key1 : key0;
   const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 t = key[i];
-    if (t == kInvalid) continue;  // (invalid keys sort last)
-    if (i == 0 || key[i - 1] != t) tile_beg[t] = dest[i];
-    if (i + 1 == n || key[i + 1] != t) tile_end[t] = dest[i] + len[i];
+    const u32 k = key[i];
+    if (k == kInvalid) continue;  // (invalid keys sort last)
+    const u32 t = k >> slab_shift;
+    if (i == 0 || (key[i - 1] >> slab_shift) != t) tile_beg[t] = dest[i];
+    if (i + 1 == n || (key[i + 1] >> slab_shift) != t) tile_end[t] = dest[i] + len[i];  // (an invalid neighbour shifts to another id)
   }
 }
 __global__ void __launch_bounds__(256) k_piece_expand(const u32* __restrict__ key0, const u32* __restrict__ key1, const u32* __restrict__ st0, const u32* __restrict__ st1,
@@ -1327,16 +1328,16 @@ __global__ void __launch_bounds__(256) k_piece_expand(const u32* __restrict__ ke
 // block ordinals of the frame -> piece keys = ordinal << 4 | z slab (the tile id); also what k_emit* publish for the record
 // path: the ordinal table and the key width of the sort
 __global__ void __launch_bounds__(256) k_piece_keys(LayerView L, u32* __restrict__ pkey, u32 rec_cap, u32 piece_cap, Counters* cnt, SortInfo* sort_info,
-                                                    const u32* __restrict__ touched_slots, int4* __restrict__ ord_info) {
+                                                    const u32* __restrict__ touched_slots, int4* __restrict__ ord_info, u32 slab_shift) {
   fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
   const u32 n = cnt->n_piece_slots;
   const bool overflow = cnt->n_records > rec_cap || n > piece_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     u32 bits = 4;  // ordinals are < n_touched; the invalid key's bits (all ones) must sort after every valid tile id
     while ((1ull << (bits - 4)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : bits;  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : bits - slab_shift;  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = 0;
+    sort_info->base = slab_shift;  // tiles of two z slabs (slab_shift = 1): the lowest slab bit is not part of the tile id
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (overflow) return;
@@ -1731,18 +1732,20 @@ __global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restr
 // Flush of a batch of `fill` hard records (block-wide; every thread calls it): sort the batch by voxel in LDS (stable
 // counting sort: per-voxel counts, exclusive scan, wave match-any ranks, waves in turn), then every voxel replays its run
 // in order with the reference's updateTsdfVoxel.  acc_cnt / acc_sum are scratch here (phases 1-2 are over).
-template <u32 kT>
+template <u32 kT, u32 kTS>
 __device__ __forceinline__ void tile_flush(const FrameParams& P, u32* blk, u32* acc_cnt, u32* acc_sum, const unsigned short* b_lin, const float* b_sdf,
                                            const float* b_uw, const u32* b_col, unsigned short* perm, u32* scan_lds, u32 fill, u32 tid, u32 lane, u32 wave) {
-  if (tid < kTileVox) acc_cnt[tid] = 0;
+  constexpr u32 kTV = 1u << kTS;  // voxels per tile
+  static_assert(kTV <= kT, "thread = voxel");
+  if (tid < kTV) acc_cnt[tid] = 0;
   __syncthreads();
-  for (u32 p = tid; p < fill; p += kT) atomicAdd(&acc_cnt[b_lin[p] & (kTileVox - 1u)], 1u);
+  for (u32 p = tid; p < fill; p += kT) atomicAdd(&acc_cnt[b_lin[p] & (kTV - 1u)], 1u);
   __syncthreads();
   {  // exclusive scan over the tile's voxels (thread = voxel)
-    const u32 c = (tid < kTileVox) ? acc_cnt[tid] : 0u;
+    const u32 c = (tid < kTV) ? acc_cnt[tid] : 0u;
     u32 tot;
     const u32 ex = block_exclusive_scan<kT / 64>(c, &tot, scan_lds);
-    if (tid < kTileVox) acc_sum[tid] = ex;
+    if (tid < kTV) acc_sum[tid] = ex;
   }
   __syncthreads();
   const u32 chunk = ((fill + kT - 1u) / kT) * 64u;  // positions per wave, a multiple of 64
@@ -1752,10 +1755,10 @@ __device__ __forceinline__ void tile_flush(const FrameParams& P, u32* blk, u32* 
       for (u32 p0 = wbeg; p0 < wend; p0 += 64) {
         const u32 p = p0 + lane;
         const bool valid = p < wend;
-        const u32 lin = valid ? (b_lin[p] & (kTileVox - 1u)) : 0u;
+        const u32 lin = valid ? (b_lin[p] & (kTV - 1u)) : 0u;
         u64 peers = __ballot(valid);
 #pragma unroll
-        for (u32 b = 0; b < kTileShift; ++b) {
+        for (u32 b = 0; b < kTS; ++b) {
           const bool bit = (lin >> b) & 1u;
           const u64 m = __ballot(bit);
           peers &= bit ? m : ~m;
@@ -1770,8 +1773,8 @@ __device__ __forceinline__ void tile_flush(const FrameParams& P, u32* blk, u32* 
     __syncthreads();
   }
   {
-    const u32 v = tid & (kTileVox - 1u);
-    const u32 c = (tid < kTileVox) ? acc_cnt[v] : 0u;
+    const u32 v = tid & (kTV - 1u);
+    const u32 c = (tid < kTV) ? acc_cnt[v] : 0u;
     if (c) {
       const u32 e = acc_sum[v];
       Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
@@ -1829,14 +1832,17 @@ __device__ __forceinline__ float sdf_of_record(const FrameParams& P, const RayOf
     return compute_sdf(P, y.a, gx, gy, gz);
 }
 
-template <bool kQ>
+template <bool kQ, u32 kTS>
 __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
                                                      u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
+  // kTS = log2(voxels per tile): 8 = one z slab of the block (16 tiles per block), 9 = two (fine voxels: half as many tiles,
+  // each a chain of dependent round trips, and thread = voxel uses all 512 threads)
+  constexpr u32 kTV = 1u << kTS, kTPB = 4096u >> kTS, kSlabs = kTV / 256u;
   const FrameParams P = *Pp;
-  __shared__ u32 blk[kTileVox * kWordsPerVoxel];
-  __shared__ u32 acc_sum[kTileVox];  // phases 1-2: sum of the saturating weights of a voxel; phase 3: end of the voxel's run in the sorted batch
-  __shared__ u32 acc_cnt[kTileVox];  // phases 1-2: records of the voxel | dirty << 31; phase 3: records of the voxel in the batch
-  __shared__ u32 hardbits[kTileVox / 32];
+  __shared__ u32 blk[kTV * kWordsPerVoxel];
+  __shared__ u32 acc_sum[kTV];  // phases 1-2: sum of the saturating weights of a voxel; phase 3: end of the voxel's run in the sorted batch
+  __shared__ u32 acc_cnt[kTV];  // phases 1-2: records of the voxel | dirty << 31; phase 3: records of the voxel in the batch
+  __shared__ u32 hardbits[kTV / 32];
   __shared__ float b_sdf[kHardBatch], b_uw[kHardBatch];
   __shared__ u32 b_col[kHardBatch];
   __shared__ unsigned short b_lin[kHardBatch], perm[kHardBatch];
@@ -1847,7 +1853,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (cnt->err) atomicOr(layer_err, cnt->err);
     *h_nblocks = min(*L.d_nblocks, L.capacity);
   }
-  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTilesPerBlock;
+  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTPB;
   const u32 par = V.info->parity & 1u;
   const u32* __restrict__ rec_key = V.key[par];
   const u32* __restrict__ rec_ray = V.ray[par];
@@ -1863,13 +1869,13 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
       tile_end[tile] = 0;
       any_hard_s = 0;
     }
-    const int4 info = ord_info[tile >> kSlabBits];
+    const int4 info = ord_info[tile / kTPB];
     const u32 pool = static_cast<u32>(info.w);
     if (pool == kInvalid) continue;  // (uniform; such a block's records carry invalid keys anyway)
-    const int gz = info.z + static_cast<int>(tile & (kTilesPerBlock - 1u));
-    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTilesPerBlock - 1u)) * kTileVox) * kWordsPerVoxel;
-    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kBT) blk[i] = gblk[i];
-    for (u32 v = tid; v < kTileVox; v += kBT) {
+    const int gz0 = info.z + static_cast<int>((tile & (kTPB - 1u)) * kSlabs);  // first z slab of the tile
+    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTPB - 1u)) * kTV) * kWordsPerVoxel;
+    for (u32 i = tid; i < kTV * kWordsPerVoxel; i += kBT) blk[i] = gblk[i];
+    for (u32 v = tid; v < kTV; v += kBT) {
       acc_sum[v] = 0;
       acc_cnt[v] = 0;
     }
@@ -1884,9 +1890,9 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 1 && !has1) break;
-        const u32 lin = (u ? k1 : k0) & (kTileVox - 1u);
+        const u32 lin = (u ? k1 : k0) & (kTV - 1u);
         const RayOfRecord& y = u ? y1 : y0;
-        const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+        const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), gz0 + static_cast<int>(lin >> 8));
         const float uw = update_weight(P, sdf, y.w);
         bool fold = foldable_update(P, sdf, uw);
         if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
@@ -1897,8 +1903,8 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
     __syncthreads();
     // ---- 2. fold what folds (thread = voxel) ----------------------------------------------------------------------------
     {
-      const u32 v = tid & (kTileVox - 1u);
-      const u32 c = (tid < kTileVox) ? acc_cnt[v] : 0u, count = c & 0x7FFFFFFFu;
+      const u32 v = tid & (kTV - 1u);
+      const u32 c = (tid < kTV) ? acc_cnt[v] : 0u, count = c & 0x7FFFFFFFu;
       bool hard = false;
       if (count) {
         my_updates += count;
@@ -1922,7 +1928,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
         }
       }
       const u64 hm = __ballot(hard);
-      if (lane == 0 && tid < kTileVox) {
+      if (lane == 0 && tid < kTV) {
         hardbits[wave * 2] = static_cast<u32>(hm);
         hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
         if (hm) any_hard_s = 1;
@@ -1937,7 +1943,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
         if (done || fill + kBT > kHardBatch) {
           // -- flush: sort the batch by voxel (stable), replay every voxel's run in order
           if (fill) {
-            tile_flush<kBT>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
+            tile_flush<kBT, kTS>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
             fill = 0;
           }
           if (done) break;
@@ -1947,7 +1953,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
         bool keep = false;
         u32 lin = 0;
         if (i < end) {
-          lin = rec_key[i] & (kTileVox - 1u);
+          lin = rec_key[i] & (kTV - 1u);
           keep = (hardbits[lin >> 5] >> (lin & 31u)) & 1u;
         }
         const u64 m = __ballot(keep);
@@ -1958,7 +1964,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
         if (keep) {
           const u32 r = rec_ray[i];
           const RayOfRecord y = ray_of_record<kQ>(R, r);
-          const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+          const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), gz0 + static_cast<int>(lin >> 8));
           const float uw = update_weight(P, sdf, y.w);
           b_lin[pos] = static_cast<unsigned short>(lin | (foldable_update(P, sdf, uw) ? 0x8000u : 0u));
           b_sdf[pos] = sdf;
@@ -1972,7 +1978,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
     __syncthreads();
-    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kBT) gblk[i] = blk[i];
+    for (u32 i = tid; i < kTV * kWordsPerVoxel; i += kBT) gblk[i] = blk[i];
   }
   // statistics
 #pragma unroll
@@ -2180,7 +2186,7 @@ __global__ void __launch_bounds__(kPT) k_apply_pieces(const FrameParams* __restr
         }
         for (u32 base = 0; base < T; base += kPT) {
           if (fill + kPT > kPieceBatch) {
-            tile_flush<kPT>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
+            tile_flush<kPT, kTileShift>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
             fill = 0;
           }
           const u32 s0 = base + tid;
@@ -2209,7 +2215,7 @@ __global__ void __launch_bounds__(kPT) k_apply_pieces(const FrameParams* __restr
           __syncthreads();
         }
       }
-      if (fill) tile_flush<kPT>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
+      if (fill) tile_flush<kPT, kTileShift>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
     }
     // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
     __syncthreads();
@@ -2442,6 +2448,7 @@ struct cox_integrator {
   FILE* timeline = nullptr;
   u32 grid_apply = 8192, grid_merge = 4096, grid_touch = 2048;  // grid-stride kernels: any size is correct (COX_GRID_* for experiments)
   bool piece_path = false;      // COX_APPLY=pieces (merged without anti-grazing): pieces instead of records (k_touch_pieces / k_apply_pieces)
+  u32 tile_shift = kTileShift;  // log2(voxels per tile) of the tile apply: 8 (one z slab of a block); COX_TILE=9: two
   bool piece_sort = false;      // pieces are walked and sorted, then expanded into records for k_apply_block (fine voxels; COX_PARTITION=pieces|records)
   ScanWorkspace scanws_p;       // scan of the piece lengths
   ScanWorkspace scanws_h;       // piece partition: scan over the layer's hash slots (ordinals of the stamped blocks)
@@ -2886,7 +2893,8 @@ static int stage_touch(const StageCtx& c, hipStream_t s) {
         COX_LAUNCH_WALK(kAxisCapLarge, false);
       }
 #undef COX_LAUNCH_WALK
-      hipLaunchKernelGGL(k_piece_keys, dim3(1024), dim3(256), 0, s, L, S.pkey[0], I->rcap, I->piece_cap, F.cnt, S.sort_info, S.touched_slots, S.ord_info);
+      hipLaunchKernelGGL(k_piece_keys, dim3(1024), dim3(256), 0, s, L, S.pkey[0], I->rcap, I->piece_cap, F.cnt, S.sort_info, S.touched_slots, S.ord_info,
+                         I->piece_sort ? I->tile_shift - kTileShift : 0u);
     }
     return COX_OK;
   }
@@ -2904,11 +2912,11 @@ static int stage_touch(const StageCtx& c, hipStream_t s) {
       hipLaunchKernelGGL(k_touch_wave<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
                          I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit_wave, dim3(I->grid_touch), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? 1 : 0);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? static_cast<int>(I->tile_shift) : 0);
   } else {
     hipLaunchKernelGGL(k_touch, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, F.cnt, I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? 1 : 0);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? static_cast<int>(I->tile_shift) : 0);
   }
   return COX_OK;
 }
@@ -2927,7 +2935,8 @@ static int stage_record_sort(const StageCtx& c, hipStream_t s) {
       exclusive_scan_u32(S.plen, S.pdest, &F.cnt->n_piece_slots, I->piece_cap, hint, &F.cnt->n_expanded, I->scanws_p, s);
       hipLaunchKernelGGL(k_piece_expand, dim3(8192), dim3(256), 0, s, S.pkey[0], S.pkey[1], S.pstart[0], S.pstart[1], S.prl[0], S.prl[1], S.sort_info, S.pdest,
                          S.lin8, S.rec_key[0], S.rec_ray[0], F.cnt);
-      hipLaunchKernelGGL(k_piece_tile_ranges, grid_for(hint, 256, 8192), dim3(256), 0, s, S.pkey[0], S.pkey[1], S.sort_info, S.plen, S.pdest, S.blk_beg, S.blk_end, F.cnt);
+      hipLaunchKernelGGL(k_piece_tile_ranges, grid_for(hint, 256, 8192), dim3(256), 0, s, S.pkey[0], S.pkey[1], S.sort_info, S.plen, S.pdest, S.blk_beg, S.blk_end, F.cnt,
+                         I->tile_shift - kTileShift);
     }
     return COX_OK;
   }
@@ -2958,13 +2967,19 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
   }
   if (I->block_apply) {
     if (!I->piece_sort)  // (piece partition: the ranges come with the expansion, k_piece_tile_ranges)
-      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, kTileShift);
-    if (I->method == COX_METHOD_MERGED)  // the merge leaves RayArrays::q
-      hipLaunchKernelGGL(k_apply_block<true>, dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
-                         I->layer->h_nblocks);
-    else
-      hipLaunchKernelGGL(k_apply_block<false>, dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
-                         I->layer->h_nblocks);
+      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift);
+#define COX_LAUNCH_APPLY(Q, TS)                                                                                                                               \
+  hipLaunchKernelGGL((k_apply_block<Q, TS>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err, \
+                     I->layer->h_nblocks)
+    if (I->method == COX_METHOD_MERGED) {  // the merge leaves RayArrays::q
+      if (I->tile_shift == 9)
+        COX_LAUNCH_APPLY(true, 9);
+      else
+        COX_LAUNCH_APPLY(true, 8);
+    } else {
+      COX_LAUNCH_APPLY(false, 8);
+    }
+#undef COX_LAUNCH_APPLY
     return COX_OK;
   }
   hipLaunchKernelGGL(k_apply_eval, dim3(4096), dim3(256), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.piece_front, S.piece_back, S.piece_wsum, F.cnt);
@@ -3383,6 +3398,9 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   if (method == COX_METHOD_MERGED && !cfg->enable_anti_grazing && !I->piece_path && I->block_apply) {
     I->piece_sort = (max_steps_per_ray(I) - 1) / 3 + 2 > kAxisCapSmall;
     if (const char* e = std::getenv("COX_PARTITION")) I->piece_sort = std::string(e) == "pieces";
+    // COX_TILE=9: tiles of two z slabs (512 voxels).  Half as many tiles did not help at fine voxels (1 cm: apply 0.81 -> 1.17 ms
+    // with one frame in flight): the tile apply is bound by its per-record work, not by the round trips per tile.
+    if (const char* e = std::getenv("COX_TILE")) I->tile_shift = (std::atoi(e) == 9) ? 9u : 8u;
   }
   int st = COX_OK;
   auto ev = [&](hipEvent_t* e) {

@@ -410,7 +410,8 @@ def test_async_device_path_equals_the_synchronous_one(hip, method, sub):
 
 
 @pytest.mark.parametrize("env", [{"COX_STREAMS": "2"}, {"COX_STREAMS": "6"}, {"COX_SUBMIT_THREAD": "0"}, {"COX_STREAMS": "6", "COX_SUBMIT_THREAD": "0"},
-                                 {"COX_GRAPH": "1"}, {"COX_STREAM_MAP": "001234"}])
+                                 {"COX_GRAPH": "1"}, {"COX_STREAM_MAP": "001234"}, {"COX_TILE": "9"}, {"COX_TILE": "9", "COX_PARTITION": "pieces"},
+                                 {"COX_PARTITION": "pieces"}])
 @pytest.mark.parametrize("method", ["merged", "simple"])
 def test_pipeline_configurations_give_the_same_layer(hip, monkeypatch, env, method):
     """The six stages of a frame on 2 / 4 / 6 streams (or any other map), with or without the submission thread, replayed as
