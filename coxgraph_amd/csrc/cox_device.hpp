@@ -36,7 +36,7 @@ struct FrameParams {
   const float* xyz;
   const uint8_t* rgba;
   u32 np2;  // power of two > n_points (bundling sort key layout)
-  u32 pad;
+  float sat1;  // saturating_update's threshold for an update weight of 1, rounded up: sdf >= sat1 saturates for EVERY weight >= 1
 };
 
 struct F3 {
@@ -79,10 +79,11 @@ __device__ __forceinline__ bool index_in_range(float scaled) {
   // conservative: floor(scaled + eps) must land in [-2^20, 2^20)
   return scaled > -1048575.0f && scaled < 1048575.0f;
 }
-// (float(idx) + 0.5) * size evaluated in double, narrowed to float (voxblox getCenterPointFromGridIndex)
-__device__ __forceinline__ float center_coord(int idx, float size) {
-  return static_cast<float>((static_cast<double>(static_cast<float>(idx)) + 0.5) * static_cast<double>(size));
-}
+// voxblox getCenterPointFromGridIndex: (float(idx) + 0.5) * size evaluated in double, narrowed to float.  With |idx| < 2^21
+// (index_in_range) idx + 0.5 is a float, the double product of two floats is exact (48 significant bits), and narrowing it is
+// ONE rounding to nearest: exactly what the float multiplication does.  Three float operations instead of a trip through
+// double per coordinate -- this runs once per (ray, voxel) update.
+__device__ __forceinline__ float center_coord(int idx, float size) { return (static_cast<float>(idx) + 0.5f) * size; }
 
 __device__ __forceinline__ u64 pack_key(int x, int y, int z) {
   return static_cast<u64>(static_cast<u32>(x + kIdxBias)) | (static_cast<u64>(static_cast<u32>(y + kIdxBias)) << 21) |

@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 #include <atomic>
+#include <limits>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -1392,8 +1393,11 @@ __device__ __forceinline__ VoxelRef locate_voxel(const LayerView& L, const int4*
 // summary word of a piece: bits 0..6 record count (0..64), bit 31 "foldable"
 constexpr u32 kPieceFoldable = 0x80000000u;
 // a record can be folded when it provably keeps distance == trunc and adds an integer weight
+// saturating_update's margin shrinks with the weight, so the threshold of weight 1 (P.sat1, rounded up by the host) covers every
+// integer weight: a float compare per record instead of a double division.  The sliver trunc*(1 + margin(uw)) <= sdf < sat1 is
+// merely replayed instead of folded -- any subset of the saturating records may be folded, the result is the same.
 __device__ __forceinline__ bool foldable_update(const FrameParams& P, float sdf, float uw) {
-  return saturating_update(P, sdf, uw) && uw == truncf(uw) && uw < 65536.0f;
+  return uw >= 1.0f && uw == truncf(uw) && uw < 65536.0f && sdf >= P.sat1;
 }
 
 // fold a run of foldable pieces with total integer weight wsum; false when the voxel state does not allow it
@@ -2668,6 +2672,12 @@ static FrameParams make_params(const cox_integrator* I, const float T[7], u32 n,
   P.voxel_size = I->layer->voxel_size;
   P.voxel_size_inv = I->layer->voxel_size_inv;
   P.trunc = c.default_truncation_distance;
+  {
+    const double t1 = static_cast<double>(c.default_truncation_distance) * (1.0 + 4.0 * 5.9604644775390625e-08 * (1.0 + static_cast<double>(c.max_weight)));
+    float f = static_cast<float>(t1);
+    if (static_cast<double>(f) < t1) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    P.sat1 = f;  // >= saturating_update's threshold for every update weight >= 1
+  }
   P.max_weight = c.max_weight;
   P.min_ray = c.min_ray_length_m;
   P.max_ray = c.max_ray_length_m;
