@@ -336,6 +336,9 @@ def main():
         rgba_img = torch.from_numpy(synth.frame_colors()).pin_memory()
         pinned = [torch.from_numpy(d).pin_memory() for _, _, _, d in host_frames[:nf]]
         with torch.cuda.stream(side):
+            for (T, _, _, _), hd in zip(host_frames[:5], pinned[:5]):  # untimed: first launches of the depth kernels, allocator warm-up
+                idp.integrate_depth_dev(T, hd.to("cuda", non_blocking=True).data_ptr(), rgba_img.to("cuda", non_blocking=True).data_ptr(), 640, 480, K)
+            idp.sync()
             t0 = time.perf_counter()
             for (T, _, _, _), hd in zip(host_frames[:nf], pinned):
                 dd = hd.to("cuda", non_blocking=True)

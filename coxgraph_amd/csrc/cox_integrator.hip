@@ -2464,8 +2464,9 @@ struct cox_integrator {
   bool has_producer = false;
   hipStream_t producer = nullptr;
   hipEvent_t ev_producer = nullptr, ev_inputs_read = nullptr;
-  float* own_xyz = nullptr;  // staging for host / depth inputs
-  uint8_t* own_rgba = nullptr;
+  float* own_xyz[kStageSets] = {};  // staging for host / depth inputs: one per bundle set (read by stages H .. M of the frame)
+  uint8_t* own_rgba[kStageSets] = {};
+  u32* h_depth_n = nullptr;  // pinned: point count of the depth image being converted
   u32* depth_flag = nullptr;
   u32* d_depth_n = nullptr;  // point count of the depth front end
   SortWorkspace sort_pts, sort_rec, sort_vis;  // sort_vis: the fast integrator's visit sort (runs beside the previous frame's record sort)
@@ -2576,8 +2577,10 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&B.head, cap));
     COX_TRY(dev_realloc(&B.bstart, cap));
   }
-  COX_TRY(dev_realloc(&I->own_xyz, static_cast<size_t>(cap) * 3));
-  COX_TRY(dev_realloc(&I->own_rgba, static_cast<size_t>(cap) * 4));
+  for (int k = 0; k < kStageSets; ++k) {
+    COX_TRY(dev_realloc(&I->own_xyz[k], static_cast<size_t>(cap) * 3));
+    COX_TRY(dev_realloc(&I->own_rgba[k], static_cast<size_t>(cap) * 4));
+  }
   COX_TRY(dev_realloc(&I->depth_flag, cap));
   COX_TRY(alloc_sort_ws(&I->sort_pts, cap));
   // records: the worst case (every ray at maximum length) always fits, so a frame can never overflow
@@ -3494,6 +3497,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_params), sizeof(FrameParams) * kFrameSets, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
+  if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_depth_n), sizeof(u32), hipHostMallocDefault) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK) st = dev_realloc(&I->d_depth_n, 1);
   if (st == COX_OK && method == COX_METHOD_FAST) {
     FastState& X = I->fast;
@@ -3565,7 +3569,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
   if (I->timeline_ref) (void)hipEventDestroy(I->timeline_ref);
   if (I->timeline) fclose(I->timeline);
-  std::vector<void*> ptrs = {I->own_xyz, I->own_rgba, I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
+  std::vector<void*> ptrs = {I->own_xyz[0], I->own_xyz[1], I->own_xyz[2], I->own_rgba[0], I->own_rgba[1], I->own_rgba[2], I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
                              I->scanws_f.block_sums, I->scanws_p.block_sums, I->scanws_h.block_sums};
   {
@@ -3611,6 +3615,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
+  if (I->h_depth_n) (void)hipHostFree(I->h_depth_n);
   if (I->h_params) (void)hipHostFree(I->h_params);
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
@@ -3642,11 +3647,12 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
   COX_TRY(sync_all(I));  // the staging buffers may still feed an earlier frame
+  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);  // the bundle set of the frame about to be enqueued
   if (n) {
-    COX_HIP(hipMemcpyAsync(I->own_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st[0]));
-    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba, rgba, 4 * n, hipMemcpyHostToDevice, I->st[0]));
+    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st[0]));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, I->st[0]));
   }
-  COX_TRY(integrate_device(I, T_G_C, I->own_xyz, rgba ? I->own_rgba : nullptr, static_cast<u32>(n), freespace));
+  COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace));
   return integrator_finish(I);
 }
 
@@ -3657,18 +3663,34 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   COX_HIP(hipSetDevice(I->layer->device));
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
-  COX_TRY(sync_all(I));  // staging buffers
+  // Frames stay in flight: the point list goes to the staging set of the frame's bundle set (read by its stages H .. M; the
+  // frame that used the set three frames ago is waited for in stream order), and the only host wait is for the point count.
+  if (I->submitter) I->submitter->wait_outstanding(1);
+  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
   hipStream_t s = I->st[0];
+  if (I->bs[k].used && I->st[0] != I->st[2]) COX_HIP(hipStreamWaitEvent(s, I->bs[k].done, 0));
+  if (I->has_producer) {  // the images were written on the caller's stream
+    COX_HIP(hipEventRecord(I->ev_producer, I->producer));
+    COX_HIP(hipStreamWaitEvent(s, I->ev_producer, 0));
+  }
   hipLaunchKernelGGL(k_depth_flags, grid_for(n), dim3(256), 0, s, depth_dev, n, I->depth_flag);
   exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, I->d_depth_n, I->scanws_d, s);
-  hipLaunchKernelGGL(k_depth_points, grid_for(n), dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz,
-                     I->own_rgba);
+  hipLaunchKernelGGL(k_depth_points, grid_for(n), dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz[k],
+                     I->own_rgba[k]);
+  if (I->has_producer) {  // the images are not read after this: later work on the caller's stream may overwrite / free them
+    COX_HIP(hipEventRecord(I->ev_inputs_read, s));
+    COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
+  }
   // the point count feeds the "mixed" visiting order, which is a function of N: it has to reach the host
-  Counters* tmp = &I->h_ring[0];
-  COX_HIP(hipMemcpyAsync(&tmp->n_depth_points, I->d_depth_n, sizeof(u32), hipMemcpyDeviceToHost, s));
+  COX_HIP(hipMemcpyAsync(I->h_depth_n, I->d_depth_n, sizeof(u32), hipMemcpyDeviceToHost, s));
   COX_HIP(hipStreamSynchronize(s));
-  const u32 n_pts = tmp->n_depth_points;
-  return integrate_device(I, T_G_C, I->own_xyz, I->own_rgba, n_pts, 0);
+  const u32 n_pts = *I->h_depth_n;
+  // (the staging buffers are the engine's own: no producer ordering for them)
+  const bool producer = I->has_producer;
+  I->has_producer = false;
+  const int st = integrate_device(I, T_G_C, I->own_xyz[k], I->own_rgba[k], n_pts, 0);
+  I->has_producer = producer;
+  return st;
 }
 
 int cox_integrator_set_input_stream(cox_integrator_t* I, void* hip_stream, int enable) {
