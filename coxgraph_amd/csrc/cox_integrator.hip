@@ -3180,7 +3180,7 @@ static int follow_layer(cox_integrator* I) {
 }
 
 // enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
-static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace) {
+static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace, bool caller_waits = false) {
   cox_layer* Lh = I->layer;
   struct HostTimer {
     cox_integrator* I;
@@ -3284,10 +3284,12 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipGetLastError());
     return COX_OK;
   };
-  if (I->submitter)
+  if (I->submitter && !caller_waits) {
     I->submitter->post(stage_b);
-  else
+  } else {  // a caller that waits for the frame anyway (cox_integrate_points) gains nothing from the hand-over
+    if (I->submitter) I->submitter->wait_outstanding(0);
     COX_TRY(stage_b());
+  }
   I->last_has_counts = true;
   return COX_OK;
 }
@@ -3652,7 +3654,7 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
     COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st[0]));
     if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, I->st[0]));
   }
-  COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace));
+  COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, true));
   return integrator_finish(I);
 }
 
