@@ -235,9 +235,13 @@ struct FastVisits {
 // operation that made the ray stop; a ray that never stops has reach == its whole walk)
 __device__ __forceinline__ bool fast_active(const FastVisits& V, const u32* __restrict__ reach, u32 i) { return V.sstep[i] <= reach[V.sray[i]]; }
 // sweep, part 1: eloc[i] = 1 + the last performed position before i inside i's tile (0 = none), tmax[tile] = same over the tile
+// prev_changed (both sweep kernels): the "changed" flag of the sweep before this one.  Zero means the iteration has converged:
+// both reach buffers hold the fixed point and eloc / tmax belong to it, so a sweep enqueued speculatively (the host reads the
+// flags one batch behind) returns at once instead of reproducing the fixed point.
 __global__ void __launch_bounds__(256) k_fast_scan_tiles(FastVisits V, const u32* __restrict__ reach, u32* __restrict__ eloc, u32* __restrict__ tmax,
-                                                         const Counters* cnt, u32 vcap) {
+                                                         const Counters* cnt, u32 vcap, const u32* __restrict__ prev_changed) {
   __shared__ u32 lds[4];
+  if (prev_changed && *prev_changed == 0u) return;
   const u32 n = fast_num_visits(cnt, vcap);
   const u32 n_tiles = (n + kFastTile - 1) / kFastTile;
   for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -286,8 +290,10 @@ __device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* _
 // collisions in a row" is the first lane whose run of set bits (continued from the previous 64 steps) is long enough.
 __global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collisions, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
                                                     const u32* __restrict__ tmax, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
-                                                    u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt, u32 vcap) {
+                                                    u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt, u32 vcap,
+                                                    const u32* __restrict__ prev_changed) {
   if (cnt->n_records > vcap) return;  // frame dropped (k_fast_visits): there are no visits to walk
+  if (prev_changed && *prev_changed == 0u) return;  // converged (see k_fast_scan_tiles); changed[this sweep] stays 0
   const u32 n_rays = cnt->n_rays;
   const u32 lane = lane_id();
   const u32 n_waves = (gridDim.x * blockDim.x) >> 6;

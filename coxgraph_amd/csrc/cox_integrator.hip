@@ -3095,11 +3095,14 @@ static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
     V = FastVisits{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
     delete t_fast;
     t_fast = new TimedRegion(I, COX_KC_FAST_SWEEPS, s);
+    const int round_first = sweep;
     auto enqueue = [&](int first, int count) -> int {
       for (int k = first; k < first + count; ++k) {
-        hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap);
+        // (a round's first sweep always runs: the flag before it belongs to the previous round or to k_fast_grow_caps)
+        const u32* prev = (k > round_first) ? X.d_changed + (k - 1) : nullptr;
+        hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap, prev);
         hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, X.cap, X.eloc, X.tmax, X.table_obs, X.reach[k & 1],
-                           X.reach[(k + 1) & 1], X.d_changed + k, F.cnt, vcap);
+                           X.reach[(k + 1) & 1], X.d_changed + k, F.cnt, vcap, prev);
       }
       COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
       return COX_OK;
