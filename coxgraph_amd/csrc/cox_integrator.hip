@@ -2438,6 +2438,7 @@ struct cox_integrator {
   cox_tsdf_config cfg;
   int method = 0;
   hipStream_t st[kNumStages] = {};  // stream of stage H, P, M, T, R, U (2 / 4 / 6 distinct ones, equal streams adjacent: see create)
+  hipStream_t st_alt = nullptr;     // default map: ray generation (H, P, M) of the odd frame slots runs here, beside the even slots' on st[0]
   int n_streams = 4;
   hipEvent_t ev_a2 = nullptr;  // fast: front -> record stage
   FrameSet fs[kFrameSets];
@@ -2454,6 +2455,7 @@ struct cox_integrator {
   bool piece_path = false;      // COX_APPLY=pieces (merged without anti-grazing): pieces instead of records (k_touch_pieces / k_apply_pieces)
   u32 tile_shift = kTileShift;  // log2(voxels per tile) of the tile apply: 8 (one z slab of a block); COX_TILE=9: two
   bool piece_sort = false;      // pieces are walked and sorted, then expanded into records for k_apply_block (fine voxels; COX_PARTITION=pieces|records)
+  SortWorkspace sort_pts_alt;   // bundling sort of the odd frame slots (runs beside the even slots' on st_alt)
   ScanWorkspace scanws_p;       // scan of the piece lengths
   ScanWorkspace scanws_h;       // piece partition: scan over the layer's hash slots (ordinals of the stamped blocks)
   u32 piece_cap = 0;
@@ -2525,6 +2527,11 @@ static u32 max_steps_per_ray(const cox_integrator* I) {
   return static_cast<u32>(std::min(s, 1.0e6));
 }
 
+// stream of a stage of the frame in frame slot `slot`
+static inline hipStream_t stage_stream(const cox_integrator* I, int stage, int slot) {
+  return (stage <= 2 && I->st_alt && (slot & 1)) ? I->st_alt : I->st[stage];
+}
+
 static int sync_all(cox_integrator* I) {
   if (I->submitter) {
     I->submitter->wait_outstanding(0);
@@ -2533,6 +2540,7 @@ static int sync_all(cox_integrator* I) {
   }
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
+  if (I->st_alt) COX_HIP(hipStreamSynchronize(I->st_alt));
   return COX_OK;
 }
 
@@ -2583,6 +2591,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   }
   COX_TRY(dev_realloc(&I->depth_flag, cap));
   COX_TRY(alloc_sort_ws(&I->sort_pts, cap));
+  COX_TRY(alloc_sort_ws(&I->sort_pts_alt, cap));
   // records: the worst case (every ray at maximum length) always fits, so a frame can never overflow
   // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
   I->steps_max = max_steps_per_ray(I);
@@ -2789,8 +2798,8 @@ static int stage_point_sort(const StageCtx& c, hipStream_t s) {
   if (I->method == COX_METHOD_MERGED) {
     const u32 n = I->pcap;
     TimedRegion t(I, COX_KC_POINT_SORT, s);
-    (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I), I->sort_pts,
-                               B.sort_info, s);
+    (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I),
+                               (I->st_alt && (c.slot & 1)) ? I->sort_pts_alt : I->sort_pts, B.sort_info, s);
   }
   return COX_OK;
 }
@@ -3006,7 +3015,7 @@ static const StageFn kStages[kNumStages] = {stage_hash, stage_point_sort, stage_
 // launch stage k of the frame in ctx on its stream: replay its graph (capturing it first if needed) or go eager
 static int run_stage(int k, const StageCtx& c) {
   cox_integrator* I = c.I;
-  hipStream_t s = I->st[k];
+  hipStream_t s = stage_stream(I, k, c.slot);
   tl_frame_no = c.frame;
   if (!I->use_graphs || I->profiling) return kStages[k](c, s);
   hipGraphExec_t& gx = I->graphs[k][c.slot];
@@ -3223,9 +3232,9 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   P.frame_id = ++Lh->frame_id;
   I->h_params[slot] = P;
 
-  if (I->has_producer) {  // inputs written on the caller's stream: stage A1 starts after them
+  if (I->has_producer) {  // inputs written on the caller's stream: stage H starts after them
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
-    COX_HIP(hipStreamWaitEvent(I->st[0], I->ev_producer, 0));
+    COX_HIP(hipStreamWaitEvent(stage_stream(I, 0, slot), I->ev_producer, 0));
   }
   if (I->method == COX_METHOD_FAST) {  // front (sets, sweeps) on st[0], record stage on st[2], see fast_frame
     if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-6 is done with this frame set
@@ -3249,22 +3258,24 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   // stage k + 1 of a frame follows stage k: in stream order, or behind the frame slot's hand-over event when on another stream
   auto chain = [](const StageCtx& x, int k) -> int {  // run stage k behind stage k - 1
     cox_integrator* I = x.I;
-    if (k > 0 && I->st[k] != I->st[k - 1]) COX_HIP(hipStreamWaitEvent(I->st[k], x.F->hand[k - 1], 0));
+    const hipStream_t sk = stage_stream(I, k, x.slot);
+    if (k > 0 && sk != stage_stream(I, k - 1, x.slot)) COX_HIP(hipStreamWaitEvent(sk, x.F->hand[k - 1], 0));
     COX_TRY(run_stage(k, x));
-    if (k + 1 < kNumStages && I->st[k + 1] != I->st[k]) COX_HIP(hipEventRecord(x.F->hand[k], I->st[k]));
+    if (k + 1 < kNumStages && stage_stream(I, k + 1, x.slot) != sk) COX_HIP(hipEventRecord(x.F->hand[k], sk));
     return COX_OK;
   };
+  const hipStream_t s_h = stage_stream(I, 0, slot), s_m = stage_stream(I, 2, slot);
   // H, P, M (ray generation: depends on the frame's input only)
-  if (F.used && I->st[0] != I->st[5]) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-6 is done with this frame set
-  if (B.used && I->st[0] != I->st[2]) COX_HIP(hipStreamWaitEvent(I->st[0], B.done, 0));  // frame t-3's merge is done with this bundle set
+  if (F.used && s_h != I->st[5]) COX_HIP(hipStreamWaitEvent(s_h, F.done, 0));  // frame t-6 is done with this frame set
+  if (B.used && (I->st_alt || s_h != s_m)) COX_HIP(hipStreamWaitEvent(s_h, B.done, 0));  // frame t-3's merge (on the other ray-generation stream, or on M's) is done with this bundle set
   COX_TRY(chain(ctx, 0));
-  COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
+  COX_HIP(hipEventRecord(F.params_copied, s_h));
   COX_TRY(chain(ctx, 1));
   COX_TRY(chain(ctx, 2));
-  COX_HIP(hipEventRecord(B.done, I->st[2]));
+  COX_HIP(hipEventRecord(B.done, s_m));
   B.used = true;
   if (I->has_producer) {  // the inputs are not read after the merge: later work on the caller's stream may overwrite / free them
-    COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[2]));
+    COX_HIP(hipEventRecord(I->ev_inputs_read, s_m));
     COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
   }
   COX_HIP(hipGetLastError());
@@ -3430,14 +3441,20 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   // its own) 4 202 / 1 949 / 531 -- past four the hand-overs between queues cost more than the shorter chains give back.
   I->n_streams = 4;
   if (const char* e = std::getenv("COX_STREAMS")) {
-    const int v = std::atoi(e);
+    const int v = std::atoi(e);  // ("4s" parses as 4)
     if (v == 2 || v == 4 || v == 6) I->n_streams = v;
   }
   if (method == COX_METHOD_FAST) I->n_streams = 2;  // front | record stage (graphs, if enabled, cover the record stage only)
   {
     // stage -> stream: 6: one each; 4: H P | M | T R | U; 2: H P M | T R U.  Equal streams are adjacent.
-    static const int kMap[3][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}};
-    const int* map = kMap[I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    // Default (four streams): H P M | H P M | T R | U -- ray generation depends on the frame's input only, so two frames run
+    // it side by side (even / odd frame slots), and the frame rate no longer hangs on the longest ray-generation chain (the
+    // merge of a frame with large bundles: 105 us); the layer update stays one pipeline, in frame order.
+    static const int kMap[4][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 1, 1, 2}};
+    const bool parity = I->n_streams == 4 && method != COX_METHOD_FAST && !std::getenv("COX_STREAM_MAP") &&
+                        !(std::getenv("COX_STREAMS") && std::string(std::getenv("COX_STREAMS")) == "4s");  // COX_STREAMS=4s: the staged map H P | M | T R | U
+    const int* map = kMap[parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    if (parity && st == COX_OK && hipStreamCreateWithFlags(&I->st_alt, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
     int custom[kNumStages];
     if (const char* e = std::getenv("COX_STREAM_MAP")) {  // experiments: six digits, stage -> stream, equal streams adjacent (e.g. 012334)
       bool ok = std::strlen(e) == kNumStages && e[0] == '0';
@@ -3574,7 +3591,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
   if (I->timeline_ref) (void)hipEventDestroy(I->timeline_ref);
   if (I->timeline) fclose(I->timeline);
-  std::vector<void*> ptrs = {I->own_xyz[0], I->own_xyz[1], I->own_xyz[2], I->own_rgba[0], I->own_rgba[1], I->own_rgba[2], I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_rec.counts,
+  std::vector<void*> ptrs = {I->own_xyz[0], I->own_xyz[1], I->own_xyz[2], I->own_rgba[0], I->own_rgba[1], I->own_rgba[2], I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_pts_alt.counts, I->sort_pts_alt.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
                              I->scanws_f.block_sums, I->scanws_p.block_sums, I->scanws_h.block_sums};
   {
@@ -3624,6 +3641,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   if (I->h_params) (void)hipHostFree(I->h_params);
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
+  if (I->st_alt) (void)hipStreamDestroy(I->st_alt);
   delete I;
 }
 
@@ -3653,9 +3671,10 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
   COX_TRY(sync_all(I));  // the staging buffers may still feed an earlier frame
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);  // the bundle set of the frame about to be enqueued
+  const hipStream_t s_in = stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets));
   if (n) {
-    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st[0]));
-    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, I->st[0]));
+    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, s_in));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, s_in));
   }
   COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, true));
   return integrator_finish(I);
@@ -3672,8 +3691,8 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   // frame that used the set three frames ago is waited for in stream order), and the only host wait is for the point count.
   if (I->submitter) I->submitter->wait_outstanding(1);
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
-  hipStream_t s = I->st[0];
-  if (I->bs[k].used && I->st[0] != I->st[2]) COX_HIP(hipStreamWaitEvent(s, I->bs[k].done, 0));
+  hipStream_t s = stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets));  // the frame's ray-generation stream
+  if (I->bs[k].used && (I->st_alt || I->st[0] != I->st[2])) COX_HIP(hipStreamWaitEvent(s, I->bs[k].done, 0));
   if (I->has_producer) {  // the images were written on the caller's stream
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
     COX_HIP(hipStreamWaitEvent(s, I->ev_producer, 0));
