@@ -2768,60 +2768,6 @@ static LayerView layer_view(const cox_layer* Lh) {
 }
 static int points_sort_passes(const cox_integrator* I) { return (ceil_log2(next_pow2(static_cast<u64>(I->pcap) + 1)) + 1 + 10) / 11; }
 
-static int stage_hash(const StageCtx& c, hipStream_t s) {
-  cox_integrator* I = c.I;
-  FrameSet& F = *c.F;
-  BundleSet& B = *c.B;
-  const bool by_value = (I->method == COX_METHOD_MERGED) && !I->use_graphs;
-  if (!by_value) COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
-  COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
-  if (I->method == COX_METHOD_MERGED) {
-    const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
-    {
-      TimedRegion t(I, COX_KC_BUNDLE_HASH, s);
-      // with anti-grazing the hash is read again by touch / emit (stage B1), after this frame's pslot may have been reused:
-      // that (rare) configuration keeps the memset; otherwise the frame cleans up after itself (k_bundle_clear)
-      const bool self_clean = !I->cfg.enable_anti_grazing;
-      if (!self_clean) COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
-      hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
-                         B.pslot, F.cnt);
-      hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
-      if (self_clean) hipLaunchKernelGGL(k_bundle_clear, grid_for(n), dim3(256), 0, s, F.d_params, B.pslot, F.fh_keys, F.fh_first);
-    }
-  }
-  return COX_OK;
-}
-static int stage_point_sort(const StageCtx& c, hipStream_t s) {
-  cox_integrator* I = c.I;
-  FrameSet& F = *c.F;
-  BundleSet& B = *c.B;
-  if (I->method == COX_METHOD_MERGED) {
-    const u32 n = I->pcap;
-    TimedRegion t(I, COX_KC_POINT_SORT, s);
-    (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I),
-                               (I->st_alt && (c.slot & 1)) ? I->sort_pts_alt : I->sort_pts, B.sort_info, s);
-  }
-  return COX_OK;
-}
-static int stage_merge(const StageCtx& c, hipStream_t s) {
-  cox_integrator* I = c.I;
-  FrameSet& F = *c.F;
-  BundleSet& B = *c.B;
-  const u32 n = I->pcap;
-  if (I->method == COX_METHOD_MERGED) {
-    BundleView V{{B.skey[0], B.skey[1]}, {B.sval[0], B.sval[1]}, B.sort_info};
-    // bundle boundaries: heads per tile, then the starts
-    const dim3 gt(std::max<u32>(1, (n + kBoundTile - 1) / kBoundTile));
-    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head);
-    hipLaunchKernelGGL(k_bundle_starts, gt, dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
-    TimedRegion t(I, COX_KC_MERGE, s);
-    hipLaunchKernelGGL(k_bundle_merge, dim3(I->grid_merge), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt,
-                       (I->piece_path || I->piece_sort) ? (I->small_axis_cap ? kAxisCapSmall : kAxisCapLarge) : 0u);
-  } else {
-    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, F.d_params, F.rays, F.cnt);
-  }
-  return COX_OK;
-}
 // exclusive scan of at most a few thousand ray step counts in ONE launch (the three-launch scan is latency-bound there)
 __global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ d_n, u32 n_max,
                                                      u32* __restrict__ d_total) {
@@ -2878,6 +2824,75 @@ __global__ void __launch_bounds__(1024) k_scan_small2(const u32* __restrict__ in
   }
 }
 
+static int stage_hash(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  const bool by_value = (I->method == COX_METHOD_MERGED) && !I->use_graphs;
+  if (!by_value) COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
+  if (I->method == COX_METHOD_MERGED) {
+    const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
+    {
+      TimedRegion t(I, COX_KC_BUNDLE_HASH, s);
+      // with anti-grazing the hash is read again by touch / emit (stage B1), after this frame's pslot may have been reused:
+      // that (rare) configuration keeps the memset; otherwise the frame cleans up after itself (k_bundle_clear)
+      const bool self_clean = !I->cfg.enable_anti_grazing;
+      if (!self_clean) COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
+      hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
+                         B.pslot, F.cnt);
+      hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
+      if (self_clean) hipLaunchKernelGGL(k_bundle_clear, grid_for(n), dim3(256), 0, s, F.d_params, B.pslot, F.fh_keys, F.fh_first);
+    }
+  }
+  return COX_OK;
+}
+static int stage_point_sort(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  if (I->method == COX_METHOD_MERGED) {
+    const u32 n = I->pcap;
+    TimedRegion t(I, COX_KC_POINT_SORT, s);
+    (void)radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, 0, true, points_sort_passes(I),
+                               (I->st_alt && (c.slot & 1)) ? I->sort_pts_alt : I->sort_pts, B.sort_info, s);
+  }
+  return COX_OK;
+}
+static int stage_merge(const StageCtx& c, hipStream_t s) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  BundleSet& B = *c.B;
+  const u32 n = I->pcap;
+  if (I->method == COX_METHOD_MERGED) {
+    BundleView V{{B.skey[0], B.skey[1]}, {B.sval[0], B.sval[1]}, B.sort_info};
+    // bundle boundaries: heads per tile, then the starts
+    const dim3 gt(std::max<u32>(1, (n + kBoundTile - 1) / kBoundTile));
+    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head);
+    hipLaunchKernelGGL(k_bundle_starts, gt, dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
+    {
+      TimedRegion t(I, COX_KC_MERGE, s);
+      hipLaunchKernelGGL(k_bundle_merge, dim3(I->grid_merge), dim3(256), 0, s, F.d_params, V, B.bstart, F.rays, F.cnt,
+                         (I->piece_path || I->piece_sort) ? (I->small_axis_cap ? kAxisCapSmall : kAxisCapLarge) : 0u);
+    }
+    // record offsets (and piece slots) of the rays: scanned here, on the ray-generation stream -- two frames' worth of it run
+    // side by side, the layer-update chain is the one that bounds the frame rate
+    const bool odd = I->st_alt && (c.slot & 1);
+    const ScanWorkspace& ws = odd ? I->scanws_a : I->scanws_b;
+    if (!(I->piece_path || I->piece_sort)) {
+      hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, &F.cnt->n_records);
+    } else if (I->small_axis_cap) {  // a few thousand bundles: one launch, one workgroup
+      hipLaunchKernelGGL(k_scan_small2, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_records, F.rays.pbound, F.rays.piece_off,
+                         &F.cnt->n_piece_slots, &F.cnt->n_ray_slots, I->pcap);
+    } else {  // fine voxels, 10^4-10^5 bundles: the three-kernel scans (the one-workgroup scan took 75 us at 1 cm)
+      exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_records, ws, s);
+      exclusive_scan_u32(F.rays.pbound, F.rays.piece_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_piece_slots, ws, s);
+    }
+  } else {
+    hipLaunchKernelGGL(k_rays_simple, grid_for(n), dim3(256), 0, s, F.d_params, F.rays, F.cnt);
+  }
+  return COX_OK;
+}
 static int stage_touch(const StageCtx& c, hipStream_t s) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
@@ -2889,13 +2904,6 @@ static int stage_touch(const StageCtx& c, hipStream_t s) {
     const PieceArrays PA{S.pkey[0], S.pstart[0], S.prl[0], S.pbkey};
     {
       TimedRegion t_walk(I, COX_KC_TOUCH_EMIT, s);
-      if (I->small_axis_cap) {  // a few thousand bundles: one launch, one workgroup
-        hipLaunchKernelGGL(k_scan_small2, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_records, F.rays.pbound, F.rays.piece_off,
-                           &F.cnt->n_piece_slots, &F.cnt->n_ray_slots, I->pcap);
-      } else {  // fine voxels, 10^4-10^5 bundles: the three-kernel scans (the one-workgroup scan took 75 us at 1 cm)
-        exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_records, I->scanws_b, s);
-        exclusive_scan_u32(F.rays.pbound, F.rays.piece_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_piece_slots, I->scanws_b, s);
-      }
 #define COX_LAUNCH_WALK(CAP, DEFER)                                                                                                                       \
   hipLaunchKernelGGL((k_touch_pieces<CAP, DEFER>), dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.lin8, PA, I->rcap, I->piece_cap, \
                      F.cnt, I->layer->d_err)
@@ -2921,9 +2929,7 @@ static int stage_touch(const StageCtx& c, hipStream_t s) {
     return COX_OK;
   }
   TimedRegion t_walk(I, COX_KC_TOUCH_EMIT, s);
-  if (merged)  // a few thousand bundles: one launch
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, &F.cnt->n_records);
-  else
+  if (!merged)  // (merged: the offsets are scanned at the end of stage M, off the layer-update chain)
     exclusive_scan_u32(F.rays.nsteps, F.rays.rec_off, &F.cnt->n_ray_slots, I->pcap, I->pcap, &F.cnt->n_records, I->scanws_b, s);
   if (merged) {
     // few long rays: one wave per ray (parallel DDA); the walk found by touch is handed to emit through the spare sort buffer
