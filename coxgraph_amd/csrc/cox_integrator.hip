@@ -3456,10 +3456,15 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     // Default (four streams): H P M | H P M | T R | U -- ray generation depends on the frame's input only, so two frames run
     // it side by side (even / odd frame slots), and the frame rate no longer hangs on the longest ray-generation chain (the
     // merge of a frame with large bundles: 105 us); the layer update stays one pipeline, in frame order.
-    static const int kMap[4][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 1, 1, 2}};
-    const bool parity = I->n_streams == 4 && method != COX_METHOD_FAST && !std::getenv("COX_STREAM_MAP") &&
+    // In between -- the piece partition at moderate ray lengths (2 cm: 5 * 10^6 records per frame, the layer update three times
+    // the ray generation, its kernels still latency-bound) -- the four streams go to H P M | T | R | U instead: 2 456 -> 2 910
+    // frames/s at 2 cm; at 1 cm (2.5 * 10^7 records, throughput-bound kernels) that map loses 7 %, so it keeps the default.
+    static const int kMap[5][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 1, 1, 2}, {0, 0, 0, 1, 2, 3}};
+    const bool chosen = std::getenv("COX_STREAM_MAP") || std::getenv("COX_STREAMS");
+    const bool update_heavy = !chosen && method == COX_METHOD_MERGED && I->piece_sort && (max_steps_per_ray(I) - 1) / 3 <= 200;
+    const bool parity = I->n_streams == 4 && method != COX_METHOD_FAST && !std::getenv("COX_STREAM_MAP") && !update_heavy &&
                         !(std::getenv("COX_STREAMS") && std::string(std::getenv("COX_STREAMS")) == "4s");  // COX_STREAMS=4s: the staged map H P | M | T R | U
-    const int* map = kMap[parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    const int* map = kMap[update_heavy ? 4 : parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
     if (parity && st == COX_OK && hipStreamCreateWithFlags(&I->st_alt, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
     int custom[kNumStages];
     if (const char* e = std::getenv("COX_STREAM_MAP")) {  // experiments: six digits, stage -> stream, equal streams adjacent (e.g. 012334)
