@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
     const bool overflow = cnt->n_records > rec_cap;
-    sort_info->nbits = overflow ? 0u : bits - static_cast<u32>(by_block);  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : (by_block ? min(bits - static_cast<u32>(by_block), 12u) : bits);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
     sort_info->base = static_cast<u32>(by_block);  // block apply (by_block = its tile shift): a stable partition by tile is all the global order it needs
     if (overflow) atomicOr(&cnt->err, kErrRecords);
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : bits - static_cast<u32>(by_block);  // 0 bits: every sort pass exits at once
+    sort_info->nbits = overflow ? 0u : (by_block ? min(bits - static_cast<u32>(by_block), 12u) : bits);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
     sort_info->base = static_cast<u32>(by_block);
     if (overflow) atomicOr(&cnt->err, kErrRecords);
@@ -1720,16 +1720,19 @@ constexpr u32 kTilesPerBlock = 1u << kSlabBits;
 constexpr u32 kHardBatch = 1024;
 constexpr u32 kBT = 512, kBW = kBT / 64;  // two waves per SIMD: a tile is a chain of dependent global round trips
 
-// tile id = key >> shift (records: kTileShift; pieces: 0, the key is the tile id)
-__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, const Counters* cnt, u32 shift) {
+// Record range of every BUCKET = tile id & 4095 (tile id = key >> shift): the records are partitioned by the low 12 bits of
+// the tile id in ONE stable pass whatever the number of touched blocks; up to 255 touched blocks a bucket is a tile, beyond
+// that the tiles b, b + 4096, ... share bucket b and the apply takes them in turn.  (Invalid keys fall into bucket 4095 and
+// are skipped there.)  mask == 0xFFFFFFFF: the key is the tile id itself (piece path), invalid keys have no range.
+__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, const Counters* cnt, u32 shift, u32 mask) {
   const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
   const u32* __restrict__ key = V.key[V.info->parity & 1u];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u32 k = key[i];
-    if (k == kInvalid) continue;
-    const u32 t = k >> shift;
-    if (i == 0 || (key[i - 1] >> shift) != t) tile_beg[t] = i;
-    if (i + 1 == n || (key[i + 1] >> shift) != t) tile_end[t] = i + 1;
+    if (mask == 0xFFFFFFFFu && k == kInvalid) continue;
+    const u32 t = (k >> shift) & mask;
+    if (i == 0 || ((key[i - 1] >> shift) & mask) != t) tile_beg[t] = i;
+    if (i + 1 == n || ((key[i + 1] >> shift) & mask) != t) tile_end[t] = i + 1;
   }
 }
 
@@ -1836,7 +1839,7 @@ __device__ __forceinline__ float sdf_of_record(const FrameParams& P, const RayOf
     return compute_sdf(P, y.a, gx, gy, gz);
 }
 
-template <bool kQ, u32 kTS>
+template <bool kQ, u32 kTS, bool kBucket>
 __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
                                                      u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
   // kTS = log2(voxels per tile): 8 = one z slab of the block (16 tiles per block), 9 = two (fine voxels: half as many tiles,
@@ -1850,7 +1853,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
   __shared__ float b_sdf[kHardBatch], b_uw[kHardBatch];
   __shared__ u32 b_col[kHardBatch];
   __shared__ unsigned short b_lin[kHardBatch], perm[kHardBatch];
-  __shared__ u32 wsum[kBW], scan_lds[kBW], any_hard_s;
+  __shared__ u32 wsum[kBW], scan_lds[kBW], any_hard_s, any_rec_s;
   // last kernel of the frame: make this frame's error bits sticky until the host next looks, and leave the layer's block
   // count where the host can read it without a sync (pinned word; it decides when to grow the pool)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1864,14 +1867,19 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const bool exact_cap = P.max_weight <= 16711680.0f;  // 2^24 - 2^16: w + u never leaves the exact integers before the cap applies
   u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
-  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const u32 beg = tile_beg[tile], end = tile_end[tile];
+  // kBucket (records partitioned in one pass by tile id & 4095): a unit is a bucket; the tiles unit, unit + 4096, ... share its
+  // record range and are taken in turn, each looking at its own records only.  Otherwise a unit is a tile.
+  const u32 n_units = kBucket ? min(n_tiles, 4096u) : n_tiles;
+  for (u32 unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const u32 beg = tile_beg[unit], end = tile_end[unit];
     if (end <= beg) continue;  // (uniform) no record touches this slab of the block
+   for (u32 tile = unit; tile < n_tiles; tile += (kBucket ? 4096u : n_tiles)) {
     __syncthreads();           // everybody has read its range and is done with the previous tile's LDS
     if (tid == 0) {
-      tile_beg[tile] = 0;  // leave the tables empty for the next frame
-      tile_end[tile] = 0;
+      tile_beg[unit] = 0;  // leave the tables empty for the next frame
+      tile_end[unit] = 0;
       any_hard_s = 0;
+      any_rec_s = 0;
     }
     const int4 info = ord_info[tile / kTPB];
     const u32 pool = static_cast<u32>(info.w);
@@ -1894,6 +1902,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 1 && !has1) break;
+        if (kBucket && ((u ? k1 : k0) >> kTS) != tile) continue;  // another tile of the bucket (or an invalid key)
         const u32 lin = (u ? k1 : k0) & (kTV - 1u);
         const RayOfRecord& y = u ? y1 : y0;
         const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), gz0 + static_cast<int>(lin >> 8));
@@ -1937,8 +1946,10 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
         hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
         if (hm) any_hard_s = 1;
       }
+      if (kBucket && count) any_rec_s = 1;  // (same value from every writer)
     }
     __syncthreads();
+    if (kBucket && !any_rec_s) continue;  // (uniform) a tile of the bucket without records of its own in this slab: nothing to write
     // ---- 3. the hard voxels: ordered replay ---------------------------------------------------------------------------
     if (any_hard_s) {
       u32 fill = 0;
@@ -1957,8 +1968,9 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
         bool keep = false;
         u32 lin = 0;
         if (i < end) {
-          lin = rec_key[i] & (kTV - 1u);
-          keep = (hardbits[lin >> 5] >> (lin & 31u)) & 1u;
+          const u32 k = rec_key[i];
+          lin = k & (kTV - 1u);
+          keep = (!kBucket || (k >> kTS) == tile) && ((hardbits[lin >> 5] >> (lin & 31u)) & 1u);
         }
         const u64 m = __ballot(keep);
         if (lane == 0) wsum[wave] = static_cast<u32>(__popcll(m));
@@ -1983,6 +1995,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
     // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
     __syncthreads();
     for (u32 i = tid; i < kTV * kWordsPerVoxel; i += kBT) gblk[i] = blk[i];
+   }
   }
   // statistics
 #pragma unroll
@@ -2971,10 +2984,11 @@ static int stage_record_sort(const StageCtx& c, hipStream_t s) {
   // 12 + ceil(log2(touched blocks + 1)) key bits, known on the device only: digits of up to 12 bits, so two passes up to
   // 4095 touched blocks (23 bits = 12 + 12 at 5 cm), three beyond.
   // Grid hint: ~2 M records keep every CU busy; larger frames grid-stride.
-  // Block apply: only the tile bits (block ordinal, z slab) are sorted -- a stable partition; one pass up to 255 touched
-  // blocks (the 5 cm frames), two beyond.
+  // Block apply: ONE stable pass on the low 12 bits of the tile id (block ordinal, z slab) whatever the number of touched
+  // blocks -- a partition into 4096 buckets; beyond 255 touched blocks several tiles share a bucket and the apply takes them
+  // in turn (k_block_starts).  No second pass is ever launched (it used to be launched every frame just to exit at 5 cm).
   (void)radix_sort_pairs<12>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true,
-                             I->block_apply ? 2 : 3, I->sort_rec, S.sort_info, s);
+                             I->block_apply ? 1 : 3, I->sort_rec, S.sort_info, s);
   return COX_OK;
 }
 static int stage_apply(const StageCtx& c, hipStream_t s) {
@@ -2988,24 +3002,30 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
   if (I->piece_path) {
     const RecordView KV{{S.pkey[0], S.pkey[1]}, {nullptr, nullptr}, S.sort_info, &F.cnt->n_piece_slots};
     const PieceView PV{{S.pkey[0], S.pkey[1]}, {S.pstart[0], S.pstart[1]}, {S.prl[0], S.prl[1]}, S.sort_info};
-    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, KV, S.blk_beg, S.blk_end, F.cnt, 0u);
+    hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, KV, S.blk_beg, S.blk_end, F.cnt, 0u, 0xFFFFFFFFu);
     hipLaunchKernelGGL(k_apply_pieces, dim3(16384), dim3(kPT), 0, s, F.d_params, F.rays, L, S.ord_info, PV, S.lin8, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err,
                        I->layer->h_nblocks);
     return COX_OK;
   }
   if (I->block_apply) {
     if (!I->piece_sort)  // (piece partition: the ranges come with the expansion, k_piece_tile_ranges)
-      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift);
-#define COX_LAUNCH_APPLY(Q, TS)                                                                                                                               \
-  hipLaunchKernelGGL((k_apply_block<Q, TS>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, I->layer->d_err, \
-                     I->layer->h_nblocks)
+      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift, 4095u);
+#define COX_LAUNCH_APPLY(Q, TS, BUCKET)                                                                                                                       \
+  hipLaunchKernelGGL((k_apply_block<Q, TS, BUCKET>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, \
+                     I->layer->d_err, I->layer->h_nblocks)
     if (I->method == COX_METHOD_MERGED) {  // the merge leaves RayArrays::q
-      if (I->tile_shift == 9)
-        COX_LAUNCH_APPLY(true, 9);
-      else
-        COX_LAUNCH_APPLY(true, 8);
+      if (I->piece_sort) {                 // tile ranges straight from the pieces (k_piece_tile_ranges)
+        if (I->tile_shift == 9)
+          COX_LAUNCH_APPLY(true, 9, false);
+        else
+          COX_LAUNCH_APPLY(true, 8, false);
+      } else if (I->tile_shift == 9) {
+        COX_LAUNCH_APPLY(true, 9, true);
+      } else {
+        COX_LAUNCH_APPLY(true, 8, true);
+      }
     } else {
-      COX_LAUNCH_APPLY(false, 8);
+      COX_LAUNCH_APPLY(false, 8, true);
     }
 #undef COX_LAUNCH_APPLY
     return COX_OK;
