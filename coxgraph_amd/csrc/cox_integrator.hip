@@ -2383,9 +2383,10 @@ struct FastState {
 };
 
 // ---- submission thread ------------------------------------------------------------------------------------------------
-// At 5 cm a frame is ~30 launches and the stream is bound by the host's launch rate, not by the GPU.  The caller's thread
-// enqueues stages A1 / A2 and returns; this thread enqueues B1 / B2 of the same frame behind it (at most one frame behind:
-// the per-slot events it records are waited for by the caller's thread two and four frames later).
+// At 5 cm a frame is 24 launches plus a dozen event operations, and on a box with slow host cores the caller's thread, not
+// the GPU, would set the frame rate.  The caller's thread enqueues ray generation (stages H, P, M) and returns; this thread
+// enqueues the layer update (T, R, U) of the same frame behind it (at most one frame behind: the per-slot events it records are
+// waited for by the caller's thread three and six frames later).
 struct Submitter {
   std::thread th;
   std::mutex m;
