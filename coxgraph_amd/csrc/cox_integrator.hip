@@ -636,9 +636,12 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Pp
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
     const bool overflow = cnt->n_records > rec_cap;
-    sort_info->nbits = overflow ? 0u : (by_block ? min(bits - static_cast<u32>(by_block), 12u) : bits);  // 0 bits: every sort pass exits at once
+    // block apply (by_block & 255 = its tile shift): a stable partition by tile is all the global order it needs; bit 8 of
+    // by_block: one pass on the low 12 bits of the tile id (buckets) is enough
+    const u32 shift = static_cast<u32>(by_block) & 255u;
+    sort_info->nbits = overflow ? 0u : ((by_block & 256) ? min(bits - shift, 12u) : bits - shift);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = static_cast<u32>(by_block);  // block apply (by_block = its tile shift): a stable partition by tile is all the global order it needs
+    sort_info->base = shift;
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (cnt->n_records > rec_cap) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -914,9 +917,10 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
     // ordinals are < n_touched; kInvalid's low bits (all ones) must sort after every valid id
     u32 bits = 12;
     while ((1ull << (bits - 12)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : (by_block ? min(bits - static_cast<u32>(by_block), 12u) : bits);  // 0 bits: every sort pass exits at once
+    const u32 shift = static_cast<u32>(by_block) & 255u;
+    sort_info->nbits = overflow ? 0u : ((by_block & 256) ? min(bits - shift, 12u) : bits - shift);  // 0 bits: every sort pass exits at once
     sort_info->parity = 0;
-    sort_info->base = static_cast<u32>(by_block);
+    sort_info->base = shift;
     if (overflow) atomicOr(&cnt->err, kErrRecords);
   }
   if (overflow) return;  // frame dropped as a whole (reported at sync); never a partial update
@@ -2467,6 +2471,7 @@ struct cox_integrator {
   FILE* timeline = nullptr;
   u32 grid_apply = 8192, grid_merge = 4096, grid_touch = 2048;  // grid-stride kernels: any size is correct (COX_GRID_* for experiments)
   bool piece_path = false;      // COX_APPLY=pieces (merged without anti-grazing): pieces instead of records (k_touch_pieces / k_apply_pieces)
+  bool bucket_partition = true;  // records partitioned in ONE pass by tile id & 4095 (coarse voxels: few touched blocks); else one or two passes on the whole tile id
   u32 tile_shift = kTileShift;  // log2(voxels per tile) of the tile apply: 8 (one z slab of a block); COX_TILE=9: two
   bool piece_sort = false;      // pieces are walked and sorted, then expanded into records for k_apply_block (fine voxels; COX_PARTITION=pieces|records)
   SortWorkspace sort_pts_alt;   // bundling sort of the odd frame slots (runs beside the even slots' on st_alt)
@@ -2954,11 +2959,11 @@ static int stage_touch(const StageCtx& c, hipStream_t s) {
       hipLaunchKernelGGL(k_touch_wave<kAxisCapLarge>, dim3(2048), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, S.rec_key[1], I->rcap, F.cnt,
                          I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit_wave, dim3(I->grid_touch), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[1], S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? static_cast<int>(I->tile_shift) : 0);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? static_cast<int>(I->tile_shift | (I->bucket_partition ? 256u : 0u)) : 0);
   } else {
     hipLaunchKernelGGL(k_touch, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.touched_slots, F.cnt, I->layer->d_err, F.fh_keys, fh_mask);
     hipLaunchKernelGGL(k_emit, grid_for(I->pcap, 256, 8192), dim3(256), 0, s, F.d_params, F.rays, L, S.rec_key[0], S.rec_ray[0], I->rcap, F.cnt, S.sort_info,
-                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? static_cast<int>(I->tile_shift) : 0);
+                       F.fh_keys, fh_mask, S.touched_slots, S.ord_info, I->block_apply ? static_cast<int>(I->tile_shift | (I->bucket_partition ? 256u : 0u)) : 0);
   }
   return COX_OK;
 }
@@ -2989,7 +2994,7 @@ static int stage_record_sort(const StageCtx& c, hipStream_t s) {
   // blocks -- a partition into 4096 buckets; beyond 255 touched blocks several tiles share a bucket and the apply takes them
   // in turn (k_block_starts).  No second pass is ever launched (it used to be launched every frame just to exit at 5 cm).
   (void)radix_sort_pairs<12>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, I->rcap, std::min<u32>(I->rcap, 1u << 21), 0, true,
-                             I->block_apply ? 1 : 3, I->sort_rec, S.sort_info, s);
+                             I->block_apply ? (I->bucket_partition ? 1 : 2) : 3, I->sort_rec, S.sort_info, s);
   return COX_OK;
 }
 static int stage_apply(const StageCtx& c, hipStream_t s) {
@@ -3010,7 +3015,7 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
   }
   if (I->block_apply) {
     if (!I->piece_sort)  // (piece partition: the ranges come with the expansion, k_piece_tile_ranges)
-      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift, 4095u);
+      hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift, I->bucket_partition ? 4095u : 0xFFFFFFFFu);
 #define COX_LAUNCH_APPLY(Q, TS, BUCKET)                                                                                                                       \
   hipLaunchKernelGGL((k_apply_block<Q, TS, BUCKET>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, \
                      I->layer->d_err, I->layer->h_nblocks)
@@ -3020,13 +3025,20 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
           COX_LAUNCH_APPLY(true, 9, false);
         else
           COX_LAUNCH_APPLY(true, 8, false);
+      } else if (!I->bucket_partition) {
+        if (I->tile_shift == 9)
+          COX_LAUNCH_APPLY(true, 9, false);
+        else
+          COX_LAUNCH_APPLY(true, 8, false);
       } else if (I->tile_shift == 9) {
         COX_LAUNCH_APPLY(true, 9, true);
       } else {
         COX_LAUNCH_APPLY(true, 8, true);
       }
-    } else {
+    } else if (I->bucket_partition) {
       COX_LAUNCH_APPLY(false, 8, true);
+    } else {
+      COX_LAUNCH_APPLY(false, 8, false);
     }
 #undef COX_LAUNCH_APPLY
     return COX_OK;
@@ -3448,6 +3460,11 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   I->piece_path = method == COX_METHOD_MERGED && !cfg->enable_anti_grazing && std::getenv("COX_APPLY") && std::string(std::getenv("COX_APPLY")) == "pieces";
   // COX_PARTITION=pieces: the walk leaves pieces, the pieces are sorted by tile and expanded into the records of the default
   // tile apply (k_touch_pieces<deferred touch> / k_piece_touch / k_piece_expand); =records: the record partition
+  // Record partition: one pass into 4096 buckets where a frame touches few blocks (coarse voxels: a bucket is a tile, or a
+  // few); where rays are long in voxels a frame touches 10^3-10^4 blocks and the tiles of a bucket would each re-read the whole
+  // bucket (1 cm: 40 of them), so the whole tile id is sorted there, in two passes (COX_BUCKETS=0|1 overrides).
+  I->bucket_partition = (max_steps_per_ray(I) - 1) / 3 + 2 <= kAxisCapSmall;
+  if (const char* e = std::getenv("COX_BUCKETS")) I->bucket_partition = std::atoi(e) != 0;
   // Default: pieces where rays are long in voxels (the large-LDS walk: 2 cm and finer with the reference's ray lengths) --
   // 1 cm 513 -> 699 frames/s, 2 cm 2 071 -> 2 159; records otherwise (5 cm: 7 129 vs 5 323, the extra launches cost more than
   // the smaller sort saves at 4 * 10^5 records per frame).

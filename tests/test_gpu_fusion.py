@@ -83,18 +83,22 @@ def test_simple_full_frame_5cm_parity(hip, oracle):
     assert rep["err_d"] <= TOL and rep["n_diff_w"] == 0
 
 
-@pytest.mark.parametrize("select", ["COX_APPLY=pieces", "COX_APPLY=records", "COX_PARTITION=records", "COX_PARTITION=pieces"])
+@pytest.mark.parametrize("select", ["COX_APPLY=pieces", "COX_APPLY=records", "COX_PARTITION=records", "COX_PARTITION=records,COX_BUCKETS=1",
+                                    "COX_PARTITION=pieces", "COX_BUCKETS=0"])
 @pytest.mark.parametrize("voxel,sub", [(0.10, 1), (0.05, 1), (0.02, 3)])
 def test_alternative_layer_update_paths_are_bit_identical(hip, oracle, monkeypatch, select, voxel, sub):
     """Environment switches (read when an integrator is created) select the other implementations of the layer-update half of
     a merged frame: COX_APPLY=pieces (k_touch_pieces / k_apply_pieces: (ray, tile) runs instead of records), COX_APPLY=records
-    (full record sort + per-record kernels, round 1), COX_PARTITION=records / pieces (the tile apply fed by the one-pass bucket
-    partition of the records -- at 2 cm ~1 500 touched blocks, six tiles per bucket -- or by sorted and expanded pieces,
-    whichever is not the default at that voxel size).  Same oracle, same bar."""
-    name, value = select.split("=")
-    monkeypatch.setenv(name, value)
+    (full record sort + per-record kernels, round 1), COX_PARTITION=records / pieces (the tile apply fed by partitioned records or
+    by sorted and expanded pieces, whichever is not the default at that voxel size), COX_BUCKETS=1 / 0 (records partitioned in one
+    pass into 4096 buckets -- at 2 cm ~1 500 touched blocks, six tiles per bucket -- or by the whole tile id in two).  Same
+    oracle, same bar."""
+    env = dict(kv.split("=") for kv in select.split(","))
+    for name, value in env.items():
+        monkeypatch.setenv(name, value)
     la, _, sa = run_frames(hip, method="merged", voxel=voxel, frames=[0, 1, 2, 40], subsample=sub, capacity_blocks=40000 if voxel < 0.05 else 8192)
-    monkeypatch.delenv(name)
+    for name in env:
+        monkeypatch.delenv(name)
     lb, _, sb = run_frames(oracle, method="merged", voxel=voxel, frames=[0, 1, 2, 40], subsample=sub, capacity_blocks=40000 if voxel < 0.05 else 8192)
     compare_stats(sa, sb)
     rep = compare_layers(la, lb)
