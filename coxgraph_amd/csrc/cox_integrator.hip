@@ -2471,6 +2471,7 @@ struct cox_integrator {
   FILE* timeline = nullptr;
   u32 grid_apply = 8192, grid_merge = 4096, grid_touch = 2048;  // grid-stride kernels: any size is correct (COX_GRID_* for experiments)
   bool piece_path = false;      // COX_APPLY=pieces (merged without anti-grazing): pieces instead of records (k_touch_pieces / k_apply_pieces)
+  u64 blocks_seen = 0, blocks_delta_max = 0;  // pool growth: last block count seen by the host, largest increase between two looks
   bool bucket_partition = true;  // records partitioned in ONE pass by tile id & 4095 (coarse voxels: few touched blocks); else one or two passes on the whole tile id
   u32 tile_shift = kTileShift;  // log2(voxels per tile) of the tile apply: 8 (one z slab of a block); COX_TILE=9: two
   bool piece_sort = false;      // pieces are walked and sorted, then expanded into records for k_apply_block (fine voxels; COX_PARTITION=pieces|records)
@@ -3201,14 +3202,24 @@ static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
 }
 
 // Layer::allocateBlockPtrByIndex never fails in voxblox.  The last kernel of every frame leaves the block count in a pinned
-// word; once the pool is half full it is doubled before the next frame is enqueued (a frame that still runs out reports
+// word; once the pool is half full (or the recent rate of allocation says it will be) it is doubled before the next frame is
+// enqueued (a frame that still runs out reports
 // COX_ERR_POOL_EXHAUSTED at sync, and so does every later frame that meets one of its blocks).  The buffers sized by the
 // layer's hash capacity follow the layer whenever it has been reallocated (by this or by cox_layer_reserve / upload).
 static int follow_layer(cox_integrator* I) {
   cox_layer* Lh = I->layer;
-  if (Lh->auto_grow && static_cast<u64>(*Lh->h_nblocks) * 2 > Lh->capacity && Lh->capacity < (1ull << 26)) {
+  // The count the host sees is up to six frames old (frames in flight), so "half full" alone reacts too late when frames
+  // allocate fast (2 cm: hundreds of blocks per frame): the largest increase seen between two looks, times the frames that may
+  // be in flight, has to fit as well (found by the 600-frame soak test with a small pool).
+  const u64 n_seen = *Lh->h_nblocks;
+  if (n_seen > I->blocks_seen) I->blocks_delta_max = std::max<u64>(I->blocks_delta_max, n_seen - I->blocks_seen);
+  I->blocks_seen = n_seen;
+  const u64 need = std::max<u64>(2 * n_seen, n_seen + 8 * I->blocks_delta_max);
+  if (Lh->auto_grow && need > Lh->capacity && Lh->capacity < (1ull << 26)) {
     COX_TRY(sync_all(I));
-    const int st = cox_internal_layer_reserve(Lh, std::min<u64>(2 * Lh->capacity, 1ull << 26));
+    u64 cap = Lh->capacity;
+    while (cap < need && cap < (1ull << 26)) cap *= 2;
+    const int st = cox_internal_layer_reserve(Lh, std::min<u64>(cap, 1ull << 26));
     if (st != COX_OK && st != COX_ERR_OUT_OF_MEMORY) return st;  // out of memory: carry on with what there is
     if (st == COX_ERR_OUT_OF_MEMORY) Lh->auto_grow = false;
   }

@@ -448,6 +448,33 @@ def test_pipeline_configurations_give_the_same_layer(hip, monkeypatch, env, meth
     assert np.array_equal(ja, jb) and np.array_equal(va, vb)
 
 
+@pytest.mark.parametrize("method,voxel,sub", [("merged", 0.05, 2), ("merged", 0.02, 4), ("fast", 0.05, 2)])
+def test_long_stream_async_equals_sync(hip, method, voxel, sub):
+    """Soak: 600 frames of the trajectory (216 degrees of the camera circle: the map and its pool keep growing) enqueued back to
+    back -- every buffer set, hand-over event and submission-thread job reused a hundred times -- against the same frames one
+    at a time through the synchronous host path."""
+    import torch
+    n_frames = 600
+    cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(voxel))
+    cap0 = 128 if voxel >= 0.05 else 4096   # small pools (the first frame alone has to fit): several doublings on the way
+    a, b = Layer(hip, voxel, capacity_blocks=cap0), Layer(hip, voxel, capacity_blocks=cap0)
+    ia, ib = Integrator(hip, a, cfg, method), Integrator(hip, b, cfg, method)
+    chunk = 100
+    for c0 in range(0, n_frames, chunk):
+        frames = [synth.make_frame(t) for t in range(c0, c0 + chunk)]
+        dev = [(T, torch.from_numpy(np.ascontiguousarray(p[::sub])).cuda(), torch.from_numpy(np.ascontiguousarray(c[::sub])).cuda()) for T, p, c, _ in frames]
+        torch.cuda.synchronize()
+        for T, xyz, rgba in dev:
+            ia.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), xyz.shape[0])
+        ia.sync()           # (the device tensors of the chunk go away after this)
+        for T, p, c, _ in frames:
+            ib.integrate_points(T, p[::sub], c[::sub])
+    assert ia.last_stats() == ib.last_stats()
+    ja, va = a.download()
+    jb, vb = b.download()
+    assert ja.shape[0] > 200 and np.array_equal(ja, jb) and np.array_equal(va, vb)
+
+
 def test_async_stream_with_changing_sizes_and_a_capacity_growth(hip, oracle):
     """Frames of very different sizes back to back, one of them larger than the integrator's initial capacity (buffers are
     reallocated in the middle of the stream), an empty one in between; checked against the oracle."""
