@@ -295,6 +295,9 @@ struct cox_projective {
   u32 layer_generation = 0;
   cox_frame_stats last{};
   bool pending = false;
+  hipEvent_t ring[4] = {};  // end of the last four frames: at most four are in flight (bounds how old the host's view of the pool is)
+  uint64_t frames = 0;
+  u64 blocks_seen = 0, blocks_delta_max = 0;
 };
 
 #define COX_TRY(expr)              \
@@ -310,6 +313,8 @@ void cox_proj_destroy(cox_projective* P) {
   for (void* q : {static_cast<void*>(P->range), static_cast<void*>(P->touched_slots), static_cast<void*>(P->cnt), static_cast<void*>(P->own_xyz)})
     if (q) (void)hipFree(q);
   if (P->h_cnt) (void)hipHostFree(P->h_cnt);
+  for (hipEvent_t e : P->ring)
+    if (e) (void)hipEventDestroy(e);
   if (P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
 }
@@ -325,6 +330,7 @@ int cox_proj_create(cox_layer* layer, const cox_tsdf_config* cfg, cox_projective
   P->layer_generation = layer->generation;
   const size_t px = static_cast<size_t>(cfg->sensor_horizontal_resolution) * cfg->sensor_vertical_resolution;
   bool ok = hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t& e : P->ring) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&P->range), sizeof(u32) * px) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&P->cnt), sizeof(ProjCounters)) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&P->h_cnt), sizeof(ProjCounters), hipHostMallocDefault) == hipSuccess;
@@ -369,10 +375,18 @@ int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev
   // Frames queue up on ONE in-order stream: the range image, the counters and the marked-block list are cleared / rewritten
   // by the frame itself, so a frame needs no host-side wait for its predecessor; statistics and errors are those of the last
   // frame / sticky in the layer's error word and are read when somebody asks (sync, last_stats).
-  // Layer::allocateBlockPtrByIndex never fails upstream: double the pool once it is half full
-  if (L->auto_grow && static_cast<u64>(*L->h_nblocks) * 2 > L->capacity && L->capacity < (1ull << 26)) {
+  // Layer::allocateBlockPtrByIndex never fails upstream: double the pool once it is half full -- or will be, at the rate blocks
+  // have been allocated lately (the host's view of the count is up to four frames old)
+  if (P->frames >= 4) COX_HIP(hipEventSynchronize(P->ring[P->frames & 3]));  // frame t-4 is done
+  const u64 n_seen = *L->h_nblocks;
+  if (n_seen > P->blocks_seen) P->blocks_delta_max = std::max<u64>(P->blocks_delta_max, n_seen - P->blocks_seen);
+  P->blocks_seen = n_seen;
+  const u64 need = std::max<u64>(2 * n_seen, n_seen + 6 * P->blocks_delta_max);
+  if (L->auto_grow && need > L->capacity && L->capacity < (1ull << 26)) {
     COX_HIP(hipStreamSynchronize(s));
-    const int st = cox_internal_layer_reserve(L, std::min<u64>(2 * L->capacity, 1ull << 26));
+    u64 cap = L->capacity;
+    while (cap < need && cap < (1ull << 26)) cap *= 2;
+    const int st = cox_internal_layer_reserve(L, std::min<u64>(cap, 1ull << 26));
     if (st != COX_OK && st != COX_ERR_OUT_OF_MEMORY) return st;
     if (st == COX_ERR_OUT_OF_MEMORY) L->auto_grow = false;
   }
@@ -430,6 +444,8 @@ int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev
   hipLaunchKernelGGL(k_proj_update, dim3(8192), dim3(256), 0, s, pp, P->range, PL, P->touched_slots, P->cnt, L->d_err, L->h_nblocks);
   COX_HIP(hipMemcpyAsync(P->h_cnt, P->cnt, sizeof(ProjCounters), hipMemcpyDeviceToHost, s));
   COX_HIP(hipEventRecord(L->last_write, s));
+  COX_HIP(hipEventRecord(P->ring[P->frames & 3], s));
+  P->frames += 1;
   L->has_write = true;
   P->pending = true;
   COX_HIP(hipGetLastError());
