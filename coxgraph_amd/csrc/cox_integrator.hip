@@ -2399,9 +2399,16 @@ struct Submitter {
   uint64_t posted = 0, finished = 0;
   int status = COX_OK;  // first error of a job; reported (and cleared) by the next drain
   bool stop = false;
+  bool ready = false;  // the thread has bound its device
   int device = 0;
   void run() {
     (void)hipSetDevice(device);
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lk(m);
+      ready = true;
+    }
+    cv_done.notify_all();
     for (;;) {
       std::function<int()> job;
       {
@@ -3208,13 +3215,13 @@ static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
 // layer's hash capacity follow the layer whenever it has been reallocated (by this or by cox_layer_reserve / upload).
 static int follow_layer(cox_integrator* I) {
   cox_layer* Lh = I->layer;
-  // The count the host sees is up to six frames old (frames in flight), so "half full" alone reacts too late when frames
+  // The count the host sees is up to a dozen frames old (frames in flight), so "half full" alone reacts too late when frames
   // allocate fast (2 cm: hundreds of blocks per frame): the largest increase seen between two looks, times the frames that may
   // be in flight, has to fit as well (found by the 600-frame soak test with a small pool).
   const u64 n_seen = *Lh->h_nblocks;
   if (n_seen > I->blocks_seen) I->blocks_delta_max = std::max<u64>(I->blocks_delta_max, n_seen - I->blocks_seen);
   I->blocks_seen = n_seen;
-  const u64 need = std::max<u64>(2 * n_seen, n_seen + 8 * I->blocks_delta_max);
+  const u64 need = std::max<u64>(2 * n_seen, n_seen + 12 * I->blocks_delta_max);  // (host ahead of stage H by <= 6 frames, H ahead of U by <= 6)
   if (Lh->auto_grow && need > Lh->capacity && Lh->capacity < (1ull << 26)) {
     COX_TRY(sync_all(I));
     u64 cap = Lh->capacity;
@@ -3610,10 +3617,17 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     if (I->submitter) {
       I->submitter->device = layer->device;
       I->submitter->th = std::thread([sub = I->submitter] { sub->run(); });
+      {
+        // the thread's first HIP call initialises per-thread runtime state: let it finish before the caller goes on making
+        // HIP calls of its own (a caller's next call once failed with a stray "invalid device ordinal" right after a create)
+        std::unique_lock<std::mutex> lk(I->submitter->m);
+        I->submitter->cv_done.wait(lk, [&] { return I->submitter->ready; });
+      }
       std::lock_guard<std::mutex> lk(g_submitters_mutex);
       g_submitters.push_back(I->submitter);
     }
   }
+  (void)hipGetLastError();  // nothing of ours stays in the thread's sticky error slot (other HIP users in the process check it after their own calls)
   *out = I;
   return COX_OK;
 }
@@ -3703,6 +3717,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
   if (I->st_alt) (void)hipStreamDestroy(I->st_alt);
   delete I;
+  (void)hipGetLastError();
 }
 
 int cox_integrate_points_dev(cox_integrator_t* I, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace) {
