@@ -186,7 +186,9 @@ def main():
         layer = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
         integ = Integrator(eng, layer, cfg, method)
         if timed_events:
-            integ.set_profiling(2 if steps < 64 else 4)  # every 2nd frame of a short run (>= 10 samples at --steps 20; timing every frame cost 13 % of its throughput), every 4th otherwise (< 2 %)
+            # timed events are not free (a timestamped marker serialises its stream: 7 % of the throughput at every 4th frame):
+            # every 2nd frame of a short run (10 samples at --steps 20), every 8th otherwise (37 samples at the default 300)
+            integ.set_profiling(2 if steps < 64 else 8)
         clock_ramp(method)
         for i in range(args.warmup):
             T, xyz, rgba, n = dev_frames[i]
@@ -254,7 +256,7 @@ def main():
                 "traffic_scope": "whole frame: sum over all kernels of (FETCH_SIZE + WRITE_SIZE) per launch x launches per frame", "traffic_source": src,
                 "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": frames_timed,
                 "launch_unit": "one frame's launches of this kernel class (HIP events around the class on its own stream)",
-                "timing": ("HIP events inside the timed region, every 2nd frame" if steps < 64 else "HIP events inside the timed region, every 4th frame") if live is not None
+                "timing": ("HIP events inside the timed region, every 2nd frame" if steps < 64 else "HIP events inside the timed region, every 8th frame") if live is not None
                           else "HIP events, one frame in flight",
                 "class_ms_per_frame": per_frame_ms, "class_ms_per_frame_one_in_flight": {k: v[0] / max(serial["apply"][1], 1) for k, v in serial.items() if v[1]},
                 "whole_frame_algorithmic_GBps": None,
