@@ -1000,1262 +1000,12 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
   }
 }
 
-// ---- piece path (merged, no anti-grazing): the walk is written once, as bytes, and partitioned by PIECES ---------------------
-// Instead of one (voxel id, ray) record per step -- 8 B written, sorted twice and read again -- the walk leaves
-//   one piece per (ray, tile) run (piece_bound), at slot piece_off[r] + k:  key = hash slot of the block << 4 | z & 15,
-//                                                 start = the slot itself,  raylen = ray << 5 | steps (<= 31), and
-//   lin8[32 * slot + j]    the voxel's (x & 15) | (y & 15) << 4 inside its tile for step j of the piece: one byte per step,
-//                          a piece's bytes in one aligned 32-B segment (eight lanes read a piece with one dword load each).
-// Only the pieces (a sixth to a tenth of the records) are sorted by tile; k_apply_pieces gathers each tile's steps through
-// them.  Slots of a ray's bound that it does not use carry the invalid key.
-struct PieceArrays {
-  u32* key;     // [piece slots]
-  u32* start;
-  u32* raylen;
-  u64* bkey;    // deferred touch only: the piece's block key (k_piece_touch turns it into the hash slot)
-};
-constexpr u32 kPieceLenBits = 5;
-
-// kDefer: the walk touches no block itself (a hash probe and a stamp check are two dependent global round trips per round of
-// 64 steps, and the wave waits for the slowest of its lanes: they were 2/3 of the walk's time at 1 cm); it leaves the block
-// key with every piece (key word = z slab for now) and k_piece_touch does all the touching at once, one thread per piece.
-template <u32 kAxisCap, bool kDefer>
-__global__ void __launch_bounds__(256) k_touch_pieces(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, u32* __restrict__ touched_slots, uint8_t* __restrict__ lin8,
-                                                      PieceArrays PA, u32 rec_cap, u32 piece_cap, Counters* cnt, u32* layer_err) {
-  const FrameParams P = *Pp;
-  __shared__ float lds_t[4][3 * kAxisCap];
-  __shared__ u32 lds_path[4][3 * kAxisCap];
-  const u32 n_slots = uniform_u32(cnt->n_ray_slots);
-  const bool overflow = uniform_u32(cnt->n_records) > rec_cap || uniform_u32(cnt->n_piece_slots) > piece_cap;  // frame dropped (k_piece_keys reports it)
-  const u32 lane = lane_id();
-  const u32 wave = threadIdx.x >> 6;
-  float* tl = lds_t[wave];
-  u32* path = lds_path[wave];
-  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_slots; r += waves_total) {
-    const u32 ns = uniform_u32(R.nsteps[r]);
-    if (ns == 0) continue;
-    const bool clearing = (uniform_u32(R.flags[r]) & 2u) != 0;
-    const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
-    const u32 poff = uniform_u32(R.piece_off[r]), bound = uniform_u32(R.pbound[r]);
-    Dda d;
-    dda_setup(d, P, pg, clearing);
-    u32 pk = 0;  // pieces of this ray so far
-    if (wave_ray_path<kAxisCap>(d, ns, tl, path, lane)) {
-      u64 carry_key = kEmptyKey;
-      u32 carry_slot = kInvalid;
-      for (u32 base = 0; base < ns; base += 64) {
-        const u32 s = base + lane;
-        const bool act = s < ns;
-        u64 bkey = kEmptyKey;
-        u32 zs = 0, lin = 0;
-        if (act) {
-          const u32 p = path[s];
-          const int x = d.c[0] + static_cast<int>(p & 1023u) * d.sgn[0];
-          const int y = d.c[1] + static_cast<int>((p >> 10) & 1023u) * d.sgn[1];
-          const int z = d.c[2] + static_cast<int>(p >> 20) * d.sgn[2];
-          lin = static_cast<u32>((x & 15) | ((y & 15) << 4));
-          bkey = pack_key(x >> 4, y >> 4, z >> 4);
-          zs = static_cast<u32>(z & 15);
-        }
-        u64 prev_key = __shfl_up(bkey, 1, 64);
-        if (lane == 0) prev_key = carry_key;
-        const bool bhead = act && bkey != prev_key;
-        u32 slot = kInvalid;
-        if constexpr (!kDefer)
-          if (bhead) slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
-        // every lane takes the slot of the nearest block head at or below it, or the carry of the previous round
-        const u64 bheads = __ballot(bhead);
-        const u64 upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-        const u64 b_below = bheads & upto;
-        const int src = b_below ? (63 - __clzll(static_cast<long long>(b_below))) : 0;
-        const u32 head_slot = static_cast<u32>(__shfl(static_cast<int>(slot), src, 64));
-        const u32 my_slot = b_below ? head_slot : carry_slot;
-        const u32 prev_z = static_cast<u32>(__shfl_up(static_cast<int>(zs), 1, 64));
-        const bool thead = act && (lane == 0 || bhead || zs != prev_z);
-        const u64 theads = __ballot(thead);
-        // the step's byte, at its offset inside its piece (lane 0 is a head: every lane has one at or below it)
-        if constexpr (kAxisCap * 3 * sizeof(float) >= 64 * 32) {
-          // staged in LDS (the crossing times are not needed any more) and written out as whole 32-B slots: the pieces of a
-          // round are consecutive slots, so the wave streams np x 32 contiguous bytes instead of 64 scattered bytes
-          uint8_t* stage = reinterpret_cast<uint8_t*>(tl);
-          if (act) {
-            const u64 t_below = theads & upto;
-            const u32 kl = static_cast<u32>(__popcll(t_below)) - 1u;
-            const u32 hl = 63u - static_cast<u32>(__clzll(static_cast<long long>(t_below)));
-            stage[kl * 32u + (lane - hl)] = static_cast<uint8_t>(lin);
-          }
-          wave_lds_handover();
-          const u32 ndw = static_cast<u32>(__popcll(theads)) * 8u;
-          const u32* stage32 = reinterpret_cast<const u32*>(tl);
-          u32* out32 = reinterpret_cast<u32*>(lin8);
-          if (!overflow)
-            for (u32 i = lane; i < ndw; i += 64)
-              if (pk + (i >> 3) < bound) out32[static_cast<size_t>(poff + pk) * 8u + i] = stage32[i];
-          wave_lds_handover();
-        } else if (act && !overflow) {
-          const u64 t_below = theads & upto;
-          const u32 k = pk + static_cast<u32>(__popcll(t_below)) - 1u;
-          const u32 hl = 63u - static_cast<u32>(__clzll(static_cast<long long>(t_below)));
-          if (k < bound) lin8[static_cast<size_t>(poff + k) * 32u + (lane - hl)] = static_cast<uint8_t>(lin);
-        }
-        if (thead && !overflow) {
-          const u32 k = pk + static_cast<u32>(__popcll(theads & ((1ull << lane) - 1ull)));
-          const u64 above = (lane == 63) ? 0ull : (theads >> (lane + 1));
-          const u32 round_end = min(64u, ns - base);
-          const u32 nxt = above ? (lane + static_cast<u32>(__ffsll(static_cast<long long>(above)))) : round_end;
-          if (k < bound) {
-            if constexpr (kDefer) {
-              PA.key[poff + k] = zs;
-              PA.bkey[poff + k] = bkey;
-            } else {
-              PA.key[poff + k] = (my_slot == kInvalid) ? kInvalid : ((my_slot << 4) | zs);
-            }
-            PA.start[poff + k] = poff + k;
-            PA.raylen[poff + k] = (r << kPieceLenBits) | (nxt - lane);
-          } else {
-            atomicOr(&cnt->err, kErrRecords);
-          }
-        }
-        pk += static_cast<u32>(__popcll(theads));
-        carry_key = __shfl(bkey, 63, 64);
-        carry_slot = static_cast<u32>(__shfl(static_cast<int>(my_slot), 63, 64));
-      }
-      wave_lds_handover();  // the next ray of this wave reuses the LDS scratch
-    } else {
-      // sequential fallback (lane 0)
-      if (lane == 0) {
-        u64 last_bkey = kEmptyKey;
-        u32 last_slot = kInvalid, last_z = 0, run = 0;
-        for (u32 s = 0; s < ns; ++s) {
-          const int x = d.c[0], y = d.c[1], z = d.c[2];
-          dda_step(d);
-          const u64 bkey = pack_key(x >> 4, y >> 4, z >> 4);
-          const u32 zs = static_cast<u32>(z & 15);
-          bool head = (s == 0) || zs != last_z || run == 31u;
-          if (bkey != last_bkey) {
-            last_bkey = bkey;
-            if constexpr (!kDefer) last_slot = touch_block(P, L, bkey, touched_slots, cnt, layer_err);
-            head = true;
-          }
-          last_z = zs;
-          if (overflow) continue;
-          if (head) {
-            if (pk < bound) {
-              if constexpr (kDefer) {
-                PA.key[poff + pk] = zs;
-                PA.bkey[poff + pk] = bkey;
-              } else
-                PA.key[poff + pk] = (last_slot == kInvalid) ? kInvalid : ((last_slot << 4) | zs);
-              PA.start[poff + pk] = poff + pk;
-              PA.raylen[poff + pk] = (r << kPieceLenBits) | 1u;
-            } else {
-              atomicOr(&cnt->err, kErrRecords);
-            }
-            pk += 1;
-            run = 0;
-          } else if (pk <= bound) {
-            PA.raylen[poff + pk - 1] += 1u;
-          }
-          if (pk <= bound) lin8[static_cast<size_t>(poff + pk - 1) * 32u + run] = static_cast<uint8_t>((x & 15) | ((y & 15) << 4));
-          run += 1;
-        }
-      }
-      pk = static_cast<u32>(__shfl(static_cast<int>(pk), 0, 64));
-    }
-    // the slots of the bound this ray did not use
-    if (!overflow)
-      for (u32 i = pk + lane; i < bound; i += 64) PA.key[poff + i] = kInvalid;
-  }
-}
-
-// deferred touch: one thread per piece slot.  Consecutive pieces of a ray mostly stay in one block (z slab changes), so only
-// the first piece of a run of equal block keys touches the block; the others take its slot through the wave.
-// touch_block without the ordinal: insert, give a fresh block its storage, stamp.  The stamp is a plain store (every
-// writer of a frame stores the same value); ordinals come from a scan over the stamps afterwards (k_ord_flags / k_ord_scatter)
-// instead of one atomicAdd per touched block on ONE word (10^4 blocks per frame at 1 cm = 114 us at 88 atomics / us).
-__device__ __forceinline__ u32 touch_block_stamp(const FrameParams& P, const LayerView& L, u64 bkey, Counters* cnt, u32* layer_err) {
-  bool fresh;
-  const u32 slot = ht_insert(L.ht_keys, L.ht_mask, bkey, &fresh);
-  if (slot == kInvalid) {
-    atomicOr(layer_err, kErrTable);
-    return kInvalid;
-  }
-  if (fresh) {
-    const u32 pool = atomicAdd(L.d_nblocks, 1u);
-    if (pool < L.capacity) {
-      L.ht_vals[slot] = pool;
-      L.block_keys[pool] = bkey;
-      atomicAdd(&cnt->n_new_blocks, 1u);
-    } else {
-      atomicSub(L.d_nblocks, 1u);
-      atomicOr(layer_err, kErrPool);
-    }
-  }
-  if (L.ht_stamp[slot] != P.frame_id) L.ht_stamp[slot] = P.frame_id;
-  return slot;
-}
-// ordinals of the blocks stamped this frame: flags over the hash slots -> exclusive scan (in ht_ord) -> dense slot list
-__global__ void __launch_bounds__(256) k_ord_flags(const FrameParams* __restrict__ Pp, LayerView L) {
-  const u32 frame = Pp->frame_id, n = L.ht_mask + 1u;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) L.ht_ord[i] = (L.ht_stamp[i] == frame) ? 1u : 0u;
-}
-__global__ void __launch_bounds__(256) k_ord_scatter(const FrameParams* __restrict__ Pp, LayerView L, u32* __restrict__ touched_slots) {
-  const u32 frame = Pp->frame_id, n = L.ht_mask + 1u;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    if (L.ht_stamp[i] == frame) touched_slots[L.ht_ord[i]] = i;
-}
-constexpr u32 kPieceSeen = 512;
-__global__ void __launch_bounds__(256) k_piece_touch(const FrameParams* __restrict__ Pp, LayerView L, PieceArrays PA, u32 rec_cap, u32 piece_cap, u32* __restrict__ touched_slots,
-                                                     Counters* cnt, u32* layer_err) {
-  const FrameParams P = *Pp;
-  // The blocks around the sensor are crossed by every ray: tens of thousands of lanes probing the same few hash lines
-  // serialise in L2 (230 us at 1 cm).  A per-wave table block key -> hash slot answers the repeats from LDS.  Two words per
-  // entry, so an entry is (1) invalidated, (2) given its key, (3) given its slot by the lane whose key is found there on
-  // reading back; lanes of one wave execute these steps in order, which is why the table is not shared between waves.
-  __shared__ u64 ckey[4][kPieceSeen];
-  __shared__ u32 cslot[4][kPieceSeen];
-  for (u32 q = threadIdx.x; q < 4 * kPieceSeen; q += 256) {
-    (&ckey[0][0])[q] = kEmptyKey;
-    (&cslot[0][0])[q] = kInvalid;
-  }
-  __syncthreads();
-  const u32 n = cnt->n_piece_slots;
-  if (cnt->n_records > rec_cap || n > piece_cap) return;  // frame dropped (k_piece_keys reports it)
-  const u32 lane = lane_id(), wv = threadIdx.x >> 6;
-  const u32 n_round = (n + 63u) & ~63u;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {  // whole waves: shuffles below
-    const u32 k = (i < n) ? PA.key[i] : kInvalid;
-    const bool valid = k != kInvalid;
-    const u64 bkey = valid ? PA.bkey[i] : kEmptyKey;
-    const u64 prev = __shfl_up(bkey, 1, 64);
-    const bool head = valid && (lane == 0 || prev != bkey);
-    u32 slot = kInvalid;
-    const u32 ci = static_cast<u32>((bkey * 0x9E3779B97F4A7C15ull) >> 40) & (kPieceSeen - 1u);
-    bool miss = head;
-    if (head && ckey[wv][ci] == bkey) {
-      slot = cslot[wv][ci];
-      miss = slot == kInvalid;
-    }
-    if (miss) slot = touch_block_stamp(P, L, bkey, cnt, layer_err);
-    if (__ballot(miss)) {  // (wave-uniform) publish what was looked up
-      const bool pub = miss && slot != kInvalid;
-      if (pub) cslot[wv][ci] = kInvalid;
-      wave_lds_handover();
-      if (pub) ckey[wv][ci] = bkey;
-      wave_lds_handover();
-      if (pub && ckey[wv][ci] == bkey) cslot[wv][ci] = slot;
-      wave_lds_handover();
-    }
-    const u64 heads = __ballot(head);
-    const u64 below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const int src = below ? (63 - __clzll(static_cast<long long>(below))) : 0;
-    const u32 my_slot = static_cast<u32>(__shfl(static_cast<int>(slot), src, 64));  // (a valid lane always has a head at or below it)
-    if (valid) PA.key[i] = (my_slot == kInvalid) ? kInvalid : ((my_slot << 4) | k);
-  }
-}
-
-// ---- piece partition: pieces sorted by tile, then EXPANDED into the (voxel id, ray) records k_apply_block reads -------------
-// The record partition moves 16 B per record and pass; the pieces are 6-10 x fewer and 12 B each.  After the piece sort a
-// scan of the piece lengths gives every piece its place in the record array, and the expansion writes the records of 256
-// pieces at a time, lane = record (fully coalesced stores), finding each record's piece by binary search in LDS.
-__global__ void __launch_bounds__(256) k_piece_lens(const u32* __restrict__ key0, const u32* __restrict__ key1, const u32* __restrict__ rl0, const u32* __restrict__ rl1,
-                                                    const SortInfo* __restrict__ info, u32* __restrict__ len, const Counters* cnt) {
-  const u32 par = info->parity & 1u;
-  const u32* __restrict__ key = par ? key1 : key0;
-  const u32* __restrict__ rl = par ? rl1 : rl0;
-  const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) len[i] = (key[i] != kInvalid) ? (rl[i] & ((1u << kPieceLenBits) - 1u)) : 0u;
-}
-// record range of every tile from the sorted pieces and their scan (5-10 x fewer elements than the records k_block_starts reads)
-__global__ void __launch_bounds__(256) k_piece_tile_ranges(const u32* __restrict__ key0, const u32* __restrict__ key1, const SortInfo* __restrict__ info,
-                                                           const u32* __restrict__ len, const u32* __restrict__ dest, u32* __restrict__ tile_beg, u32* __restrict__ tile_end,
-                                                           const Counters* cnt, u32 slab_shift) {
-  const u32* __restrict__ key = (info->parity & 1u) ? key1 : key0;
-  const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 k = key[i];
-    if (k == kInvalid) continue;  // (invalid keys sort last)
-    const u32 t = k >> slab_shift;
-    if (i == 0 || (key[i - 1] >> slab_shift) != t) tile_beg[t] = dest[i];
-    if (i + 1 == n || (key[i + 1] >> slab_shift) != t) tile_end[t] = dest[i] + len[i];  // (an invalid neighbour shifts to another id)
-  }
-}
-__global__ void __launch_bounds__(256) k_piece_expand(const u32* __restrict__ key0, const u32* __restrict__ key1, const u32* __restrict__ st0, const u32* __restrict__ st1,
-                                                      const u32* __restrict__ rl0, const u32* __restrict__ rl1, const SortInfo* __restrict__ info,
-                                                      const u32* __restrict__ dest, const uint8_t* __restrict__ lin8, u32* __restrict__ rec_key, u32* __restrict__ rec_ray,
-                                                      const Counters* cnt) {
-  __shared__ u32 s_off[257], s_key[256], s_ray[256], s_slot[256], lds[4];
-  const u32 par = info->parity & 1u;
-  const u32* __restrict__ key = par ? key1 : key0;
-  const u32* __restrict__ start = par ? st1 : st0;
-  const u32* __restrict__ rl = par ? rl1 : rl0;
-  const u32 n = (cnt->err & kErrRecords) ? 0u : cnt->n_piece_slots;
-  const u32 n_chunks = (n + 255u) / 256u;
-  for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const u32 i = c * 256u + threadIdx.x;
-    u32 k = kInvalid, len = 0;
-    if (i < n) {
-      k = key[i];
-      if (k != kInvalid) {
-        const u32 v = rl[i];
-        len = v & ((1u << kPieceLenBits) - 1u);
-        s_ray[threadIdx.x] = v >> kPieceLenBits;
-        s_slot[threadIdx.x] = start[i];
-        s_key[threadIdx.x] = k << 8;  // tile id (ordinal << 4 | z slab) -> voxel id without its low byte
-      }
-    }
-    u32 tot;
-    const u32 off = block_exclusive_scan<4>(len, &tot, lds);
-    s_off[threadIdx.x] = off;
-    if (threadIdx.x == 0) s_off[256] = tot;
-    __syncthreads();
-    const u32 base = dest[c * 256u];  // records before this chunk (exclusive scan of the lengths)
-    for (u32 t = threadIdx.x; t < tot; t += 256) {
-      u32 lo = 0, hi = 256;  // the piece p with s_off[p] <= t < s_off[p + 1] (pieces of length 0 are never hit)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const u32 mid = (lo + hi) >> 1;
-        if (s_off[mid] <= t)
-          lo = mid;
-        else
-          hi = mid;
-      }
-      // among pieces with the same offset (empty ones) lo is the last: the one that holds t
-      const u32 j = t - s_off[lo];
-      rec_key[base + t] = s_key[lo] | lin8[static_cast<size_t>(s_slot[lo]) * 32u + j];
-      rec_ray[base + t] = s_ray[lo];
-    }
-    __syncthreads();
-  }
-}
-
-// block ordinals of the frame -> piece keys = ordinal << 4 | z slab (the tile id); also what k_emit* publish for the record
-// path: the ordinal table and the key width of the sort
-__global__ void __launch_bounds__(256) k_piece_keys(LayerView L, u32* __restrict__ pkey, u32 rec_cap, u32 piece_cap, Counters* cnt, SortInfo* sort_info,
-                                                    const u32* __restrict__ touched_slots, int4* __restrict__ ord_info, u32 slab_shift) {
-  fill_ord_info(L, touched_slots, ord_info, cnt->n_touched);
-  const u32 n = cnt->n_piece_slots;
-  const bool overflow = cnt->n_records > rec_cap || n > piece_cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    u32 bits = 4;  // ordinals are < n_touched; the invalid key's bits (all ones) must sort after every valid tile id
-    while ((1ull << (bits - 4)) < static_cast<u64>(cnt->n_touched) + 1ull) ++bits;
-    sort_info->nbits = overflow ? 0u : bits - slab_shift;  // 0 bits: every sort pass exits at once
-    sort_info->parity = 0;
-    sort_info->base = slab_shift;  // tiles of two z slabs (slab_shift = 1): the lowest slab bit is not part of the tile id
-    if (overflow) atomicOr(&cnt->err, kErrRecords);
-  }
-  if (overflow) return;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 k = pkey[i];
-    if (k == kInvalid) continue;
-    const u32 slot = k >> 4;
-    if (L.ht_vals[slot] == kInvalid) {
-      atomicOr(&cnt->err, kErrPool);  // block without storage: these updates are lost
-      pkey[i] = kInvalid;
-    } else {
-      pkey[i] = (L.ht_ord[slot] << 4) | (k & 15u);
-    }
-  }
-}
+#include "cox_pieces.hpp"
 
 #include "cox_fast.hpp"
 
-// ---- apply: per voxel, the running weighted-mean / clamp update in canonical ray order -----------------
-// After the stable sort the records of one voxel are contiguous ("segment") and in ray order.
-// k_apply_eval, one wave per 64 consecutive records:
-//   1. every lane evaluates its own record (voxel centre, sdf, update weight, colour) -- the costly,
-//      order-independent part -- fully in parallel;
-//   2. the head lane of every segment that ends inside the wave replays its records in order out of the
-//      neighbours' registers (__shfl), at most 63 dependent steps;
-//   3. a segment that crosses a wave boundary ("long": the few near-camera voxels that every ray crosses)
-//      is only summarised: per wave, for the piece at its front (continuing from the previous wave) and
-//      the piece at its back (starting here): record count, whether every record is a provable no-op on a
-//      voxel sitting at +trunc with an integer weight (saturating_update), and the weight sum.
-// k_apply_long, one wave per long segment: walks the piece summaries (64 pieces = 4096 records per load),
-//   folds runs of no-op pieces exactly and replays only the rest record by record.
-// No float atomics anywhere; the result is bit-reproducible and equals the sequential reference order.
-struct VoxelRef {
-  u32* ptr;  // 3 words
-  int gx, gy, gz;
-  bool ok;
-};
-// one 16-B gather per record instead of three dependent ones (ordinal -> hash slot -> block key / pool index): the emit
-// kernel leaves (16 * block index, pool index) of every block touched this frame in ord_info
-__device__ __forceinline__ VoxelRef locate_voxel(const LayerView& L, const int4* __restrict__ ord_info, u32 vid) {
-  VoxelRef v;
-  const u32 ord = vid >> 12, lin = vid & 4095u;
-  const int4 b = ord_info[ord];
-  const u32 pool = static_cast<u32>(b.w);
-  v.gx = b.x + static_cast<int>(lin & 15u);
-  v.gy = b.y + static_cast<int>((lin >> 4) & 15u);
-  v.gz = b.z + static_cast<int>(lin >> 8);
-  v.ok = pool != kInvalid;
-  v.ptr = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + lin) * kWordsPerVoxel;
-  return v;
-}
-// summary word of a piece: bits 0..6 record count (0..64), bit 31 "foldable"
-constexpr u32 kPieceFoldable = 0x80000000u;
-// a record can be folded when it provably keeps distance == trunc and adds an integer weight
-// saturating_update's margin shrinks with the weight, so the threshold of weight 1 (P.sat1, rounded up by the host) covers every
-// integer weight: a float compare per record instead of a double division.  The sliver trunc*(1 + margin(uw)) <= sdf < sat1 is
-// merely replayed instead of folded -- any subset of the saturating records may be folded, the result is the same.
-__device__ __forceinline__ bool foldable_update(const FrameParams& P, float sdf, float uw) {
-  return uw >= 1.0f && uw == truncf(uw) && uw < 65536.0f && sdf >= P.sat1;
-}
-
-// fold a run of foldable pieces with total integer weight wsum; false when the voxel state does not allow it
-__device__ __forceinline__ bool fold_pieces(const FrameParams& P, Voxel& v, u32 wsum) {
-  if (v.d != P.trunc) return false;
-  if (v.w >= P.max_weight) return true;  // min(max_weight, w + u) == max_weight for every u > 0
-  if (v.w != truncf(v.w) || v.w + static_cast<float>(wsum) >= 16777216.0f) return false;
-  v.w = std_min(P.max_weight, v.w + static_cast<float>(wsum));  // integer partial sums are exact
-  return true;
-}
-
-__global__ void __launch_bounds__(256) k_apply_eval(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ touched_slots, RecordView V,
-                                                    u32* __restrict__ piece_front, u32* __restrict__ piece_back, u32* __restrict__ piece_wsum,
-                                                    Counters* cnt) {
-  const FrameParams P = *Pp;
-  __shared__ u32 blk_updates, blk_voxels, blk_long, blk_maxrun;
-  if (threadIdx.x == 0) {
-    blk_updates = 0;
-    blk_voxels = 0;
-    blk_long = 0;
-    blk_maxrun = 0;
-  }
-  __syncthreads();
-  const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
-  const u32 par = uniform_u32(V.info->parity & 1u);
-  const u32* __restrict__ rec_key = V.key[par];
-  const u32* __restrict__ rec_ray = V.ray[par];
-  const u32 lane = lane_id();
-  const u32 n_waves = (n + 63) >> 6;
-  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  u32 my_updates = 0, my_voxels = 0, my_long = 0, my_maxrun = 0;
-  for (u32 wv = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wv < n_waves; wv += waves_total) {
-    const u32 wave_base = wv << 6;
-    const u32 i = wave_base + lane;
-    const bool in = i < n;
-    const u32 key = in ? rec_key[i] : kInvalid;
-    const u32 prev = (in && i > 0) ? rec_key[i - 1] : ~key;
-    const bool valid = in && key != kInvalid;
-    const bool boundary = !in || (key != prev) || i == 0;
-    const bool head = valid && boundary;
-    // ---- 1. per-record evaluation --------------------------------------------------------------------
-    VoxelRef vr{nullptr, 0, 0, 0, false};
-    float sdf = 0.0f, uw = 0.0f;
-    u32 color = 0;
-    bool fold = false;
-    if (valid) {
-      vr = locate_voxel(L, touched_slots, key);
-      const u32 r = rec_ray[i];
-      const F3 pg{R.px[r], R.py[r], R.pz[r]};
-      sdf = compute_sdf(P, pg, vr.gx, vr.gy, vr.gz);
-      uw = update_weight(P, sdf, R.w[r]);
-      color = R.color[r];
-      fold = foldable_update(P, sdf, uw);
-    }
-    // ---- segment geometry -----------------------------------------------------------------------------
-    const u64 bmask = __ballot(boundary);
-    const u64 later = (lane == 63) ? 0ull : (bmask >> (lane + 1));
-    u32 len = 0;
-    bool runs_on = false;  // the segment of this head continues in the next wave
-    if (head) {
-      if (later) {
-        len = static_cast<u32>(__ffsll(static_cast<long long>(later)));
-      } else {
-        const u32 nxt = wave_base + 64;
-        if (nxt >= n || rec_key[nxt] != key)
-          len = min(nxt, n) - i;
-        else
-          runs_on = true;
-      }
-    }
-    // A segment that merely straddles the wave boundary (ends inside the next wave) is finished here: the few
-    // records of its tail are evaluated by this wave too.  Only segments that cover the whole next wave are "long".
-    const u64 omask = __ballot(runs_on);
-    bool strad = false;
-    float sdf2 = 0.0f, uw2 = 0.0f;
-    u32 color2 = 0, ll = 0;
-    if (omask) {
-      ll = static_cast<u32>(__ffsll(static_cast<long long>(omask))) - 1u;
-      const u32 lkey = static_cast<u32>(__builtin_amdgcn_readlane(key, ll));
-      const u32 j = wave_base + 64 + lane;
-      const bool in2 = (j < n) && (rec_key[j] == lkey);
-      const u32 e2 = static_cast<u32>(__popcll(__ballot(in2)));  // the tail is contiguous: lanes [0, e2)
-      if (e2 < 64) {
-        strad = true;
-        const int gx = __builtin_amdgcn_readlane(vr.gx, ll), gy = __builtin_amdgcn_readlane(vr.gy, ll), gz = __builtin_amdgcn_readlane(vr.gz, ll);
-        if (in2) {
-          const u32 r = rec_ray[j];
-          const F3 pg{R.px[r], R.py[r], R.pz[r]};
-          sdf2 = compute_sdf(P, pg, gx, gy, gz);
-          uw2 = update_weight(P, sdf2, R.w[r]);
-          color2 = R.color[r];
-        }
-        if (lane == ll) len = (64u - ll) + e2;
-      }
-    }
-    const bool is_long = runs_on && !strad;
-    // ---- 2. short segments: head lanes replay their records in order ----------------------------------
-    const bool run_short = head && !is_long && vr.ok;
-    Voxel v{0.0f, 0.0f, 0u};
-    if (run_short) {
-      v.d = __uint_as_float(vr.ptr[0]);
-      v.w = __uint_as_float(vr.ptr[1]);
-      v.c = vr.ptr[2];
-    }
-    // Most records of a frame lie in free space (saturating_update: distance stays == trunc, an integer weight is
-    // added).  A short segment that consists of such records only, on a voxel in the matching state, is folded in one
-    // step exactly like the pieces of a long segment (fold_pieces) instead of being replayed record by record; what is
-    // left to replay decides how long this wave's loop runs.
-    bool folded = false;
-    {
-      const u64 foldmask = __ballot(fold);
-      const u32 wi = fold ? static_cast<u32>(uw) : 0u;
-      const u32 psum = wave_inclusive_scan(wi);
-      const u32 seg_hi = static_cast<u32>(__shfl(static_cast<int>(psum), static_cast<int>((lane + len - 1u) & 63u), 64));
-      const bool inside = run_short && len > 0 && lane + len <= 64u;  // the whole segment lies in this wave's lanes
-      if (inside) {
-        const u64 seg = ((len == 64u) ? ~0ull : ((1ull << len) - 1ull)) << lane;
-        if ((foldmask & seg) == seg) folded = fold_pieces(P, v, seg_hi - (psum - wi));
-      }
-    }
-    {  // longest run of updates on one voxel (statistics only; long runs report theirs from k_apply_long)
-      u32 mr = (head && !is_long) ? len : 0u;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) mr = max(mr, static_cast<u32>(__shfl_xor(static_cast<int>(mr), off, 64)));
-      my_maxrun = max(my_maxrun, mr);
-    }
-    u32 max_len = (run_short && !folded) ? len : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(static_cast<int>(max_len), off, 64)));
-    for (u32 k = 0; k < max_len; ++k) {
-      const u32 idx = lane + k;
-      const int src = static_cast<int>(idx & 63u);
-      float s_k = __shfl(sdf, src, 64);
-      float u_k = __shfl(uw, src, 64);
-      u32 c_k = static_cast<u32>(__shfl(static_cast<int>(color), src, 64));
-      if (strad && k + ll >= 64u) {  // wave-uniform: only then can a lane reach past the wave (lane ll is the only one that does)
-        const float s_2 = __shfl(sdf2, src, 64);
-        const float u_2 = __shfl(uw2, src, 64);
-        const u32 c_2 = static_cast<u32>(__shfl(static_cast<int>(color2), src, 64));
-        if (idx >= 64u) {
-          s_k = s_2;
-          u_k = u_2;
-          c_k = c_2;
-        }
-      }
-      if (run_short && !folded && k < len) update_voxel(P, v, s_k, u_k, c_k);
-    }
-    if (run_short) {
-      vr.ptr[0] = __float_as_uint(v.d);
-      vr.ptr[1] = __float_as_uint(v.w);
-      vr.ptr[2] = v.c;
-    }
-    // ---- 3. summaries of the pieces of long segments --------------------------------------------------
-    // front piece: lanes [0, e) that continue the previous wave's last segment (e = first boundary lane)
-    const u32 e = bmask ? static_cast<u32>(__ffsll(static_cast<long long>(bmask))) - 1u : 64u;
-    {
-      const u64 fmask = (e == 64) ? ~0ull : ((1ull << e) - 1ull);
-      const bool all_fold = (__ballot(fold) & fmask) == fmask;
-      const float wf = (lane < e) ? uw : 0.0f;
-      u32 wsum = all_fold ? static_cast<u32>(wf) : 0u;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) wsum += static_cast<u32>(__shfl_xor(static_cast<int>(wsum), off, 64));
-      if (lane == 0) {
-        piece_front[wv] = e | ((all_fold && e > 0) ? kPieceFoldable : 0u);
-        piece_wsum[2 * wv] = wsum;
-      }
-    }
-    // back piece: the long segment (at most one) that starts in this wave; 0 = none
-    const u64 lmask = __ballot(is_long);
-    if (lmask) {
-      const u32 lh = static_cast<u32>(__ffsll(static_cast<long long>(lmask))) - 1u;
-      const u64 bm = ~((1ull << lh) - 1ull);
-      const bool all_fold = (__ballot(fold) & bm) == bm;
-      const float wb = (lane >= lh) ? uw : 0.0f;
-      u32 wsum = all_fold ? static_cast<u32>(wb) : 0u;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) wsum += static_cast<u32>(__shfl_xor(static_cast<int>(wsum), off, 64));
-      if (lane == lh) {
-        piece_back[wv] = (64u - lh) | (all_fold ? kPieceFoldable : 0u);
-        piece_wsum[2 * wv + 1] = wsum;
-      }
-      my_long += 1;
-    } else if (lane == 0) {
-      piece_back[wv] = 0;
-    }
-    my_updates += static_cast<u32>(__popcll(__ballot(valid)));
-    my_voxels += static_cast<u32>(__popcll(__ballot(head)));
-  }
-  if (lane == 0) {
-    if (my_updates) atomicAdd(&blk_updates, my_updates);
-    if (my_voxels) atomicAdd(&blk_voxels, my_voxels);
-    if (my_long) atomicAdd(&blk_long, my_long);
-    if (my_maxrun) atomicMax(&blk_maxrun, my_maxrun);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32* sh = cnt->shard[blockIdx.x & 63u];
-    if (blk_updates) atomicAdd(&sh[kShUpdates], blk_updates);
-    if (blk_voxels) atomicAdd(&sh[kShVoxels], blk_voxels);
-    if (blk_long) atomicAdd(&sh[kShLong], blk_long);
-    if (blk_maxrun) atomicMax(&sh[kShMaxRun], blk_maxrun);
-  }
-}
-
-// replay records [a, a + count) of the long segment in order (count <= 64)
-__device__ __forceinline__ void replay_piece(const FrameParams& P, const RayArrays& R, const u32* __restrict__ rec_ray, int gx, int gy, int gz, u32 a, u32 count,
-                                             u32 lane, Voxel& v) {
-  float s = 0.0f, u = 0.0f;
-  u32 c = 0;
-  if (lane < count) {
-    const u32 r = rec_ray[a + lane];
-    const F3 pg{R.px[r], R.py[r], R.pz[r]};
-    s = compute_sdf(P, pg, gx, gy, gz);
-    u = update_weight(P, s, R.w[r]);
-    c = R.color[r];
-  }
-  for (u32 k = 0; k < count; ++k) update_voxel(P, v, readlane_f32(s, k), readlane_f32(u, k), static_cast<u32>(__builtin_amdgcn_readlane(c, k)));
-}
-__global__ void __launch_bounds__(256) k_apply_long(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ touched_slots, RecordView V,
-                                                    const u32* __restrict__ piece_front, const u32* __restrict__ piece_back,
-                                                    const u32* __restrict__ piece_wsum, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
-  const FrameParams P = *Pp;
-  // last kernel of the frame: make this frame's error bits sticky until the host next looks, and leave the layer's block
-  // count where the host can read it without a sync (pinned word; it decides when to grow the pool)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (cnt->err) atomicOr(layer_err, cnt->err);
-    *h_nblocks = min(*L.d_nblocks, L.capacity);
-  }
-  const u32 n = uniform_u32((cnt->err & kErrRecords) ? 0u : *V.d_n);
-  if (n == 0) return;
-  const u32 par = uniform_u32(V.info->parity & 1u);
-  const u32* __restrict__ rec_key = V.key[par];
-  const u32* __restrict__ rec_ray = V.ray[par];
-  const u32 lane = lane_id();
-  const u32 n_waves = (n + 63) >> 6;
-  const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
-  // every record wave with a back piece owns one long segment: one wave of this kernel per record wave, so that the long
-  // segments of a frame (they cluster: the voxels of the cone in front of the sensor) are folded side by side
-  for (u32 w0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); w0 < n_waves; w0 += waves_total) {
-    {
-      const u32 pb = uniform_u32(piece_back[w0]);
-      if (pb == 0u) continue;
-      const u32 count0 = pb & 127u;
-      const u32 start = (w0 << 6) + 64u - count0;
-      const VoxelRef vr = locate_voxel(L, touched_slots, uniform_u32(rec_key[start]));
-      if (!vr.ok) continue;
-      Voxel v{__uint_as_float(vr.ptr[0]), __uint_as_float(vr.ptr[1]), vr.ptr[2]};
-      // the piece at the back of the wave that holds the head
-      if (!((pb & kPieceFoldable) && fold_pieces(P, v, uniform_u32(piece_wsum[2 * w0 + 1])))) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, start, count0, lane, v);
-      // front pieces of the following waves; the segment ends with the first piece shorter than 64
-      bool more = true;
-      u32 seg_records = count0;  // statistics: length of this voxel's run
-      for (u32 wbase = w0 + 1; more && wbase < n_waves; wbase += 64) {
-        const u32 w = wbase + lane;
-        const u32 pf = (w < n_waves) ? piece_front[w] : 0u;
-        const u32 ws = (w < n_waves) ? piece_wsum[2 * w] : 0u;
-        const u32 count = pf & 127u;
-        const u64 end_mask = __ballot(count < 64u);
-        const u32 n_use = end_mask ? static_cast<u32>(__ffsll(static_cast<long long>(end_mask))) : 64u;  // pieces [0, n_use) belong to the segment
-        if (end_mask) more = false;
-        {
-          u32 c = (lane < n_use) ? count : 0u;
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) c += static_cast<u32>(__shfl_xor(static_cast<int>(c), off, 64));
-          seg_records += c;
-        }
-        const u64 use_mask = (n_use == 64) ? ~0ull : ((1ull << n_use) - 1ull);
-        const u64 hard_mask = __ballot(!(pf & kPieceFoldable)) & use_mask;  // pieces that need a record-by-record replay
-        u32 pos = 0;
-        while (pos < n_use) {
-          const u64 hard_from = hard_mask >> pos;
-          const u32 run = hard_from ? static_cast<u32>(__ffsll(static_cast<long long>(hard_from))) - 1u : (n_use - pos);  // foldable pieces ahead
-          if (run > 0) {
-            u32 t = (lane >= pos && lane < pos + run) ? ws : 0u;  // total weight of pieces [pos, pos + run)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t += static_cast<u32>(__shfl_xor(static_cast<int>(t), off, 64));
-            if (fold_pieces(P, v, t)) {
-              pos += run;
-              continue;
-            }
-          }
-          // replay piece `pos` (hard, or the voxel is not in a foldable state yet)
-          const u32 cnt_p = static_cast<u32>(__builtin_amdgcn_readlane(count, pos));
-          if (cnt_p) replay_piece(P, R, rec_ray, vr.gx, vr.gy, vr.gz, (wbase + pos) << 6, cnt_p, lane, v);
-          pos += 1;
-        }
-      }
-      if (lane == 0) {
-        vr.ptr[0] = __float_as_uint(v.d);
-        vr.ptr[1] = __float_as_uint(v.w);
-        vr.ptr[2] = v.c;
-        atomicMax(&cnt->shard[w0 & 63u][kShMaxRun], seg_records);
-      }
-    }
-  }
-}
-
-// ---- block apply: the TSDF update with the voxel tiles staged in LDS -----------------------------------------------------
-// The records arrive PARTITIONED by tile = (block ordinal, z-slab of the block: 16 x 16 x 1 voxels = 256 voxels, 3 KB of
-// contiguous wire words) -- one or two stable radix passes on those bits; ray order inside a tile is preserved.  One
-// workgroup owns one tile (a 16^3 block is sixteen of them; a frame at 5 cm has ~10^3 tiles with records, at 1 cm ~10^5,
-// so the chip is full at every voxel size, and the near-camera blocks that every ray crosses are spread over 16 workgroups):
-//   0. the tile's voxels are read into LDS with full-line loads;
-//   1. every record of the tile is evaluated once (voxel centre, sdf, update weight) and classified: a SATURATING record
-//      (saturating_update: provably leaves distance == truncation, adds an integer weight) only needs its weight summed --
-//      per voxel, in LDS, with integer atomics (exact in any order); any other record marks its voxel "dirty";
-//   2. per voxel: if no record was dirty and the voxel sits at +truncation with an integer weight (or is unobserved), its whole
-//      run folds to  w <- min(max_weight, w + sum)  -- bit-identical to replaying it (exactness
-//      arguments) -- which is most of a frame: the free space in front of the surfaces;
-//   3. the records of the remaining ("hard") voxels -- the surface band -- are compacted in ray order, batches of 1024 are
-//      sorted by voxel in LDS (stable counting sort: wave match-any ranks), and every hard voxel replays its records in
-//      order with the reference's updateTsdfVoxel; the voxel state lives in LDS across batches;
-//   4. the tile goes back to HBM with full-line stores.
-// No float atomics; the result is the single-threaded reference order, bit for bit.  This replaces one or two of the global
-// sort passes of the record pipeline and the 12-B scatter / gather of the per-record apply kernels.
-constexpr u32 kSlabBits = 4;                               // z bits of the linear voxel index that belong to the tile id
-constexpr u32 kTileShift = 12 - kSlabBits;                 // tile id = voxel id >> kTileShift = block ordinal << 4 | z
-constexpr u32 kTileVox = 1u << kTileShift;                 // 256 voxels per tile
-constexpr u32 kTilesPerBlock = 1u << kSlabBits;
-constexpr u32 kHardBatch = 1024;
-constexpr u32 kBT = 512, kBW = kBT / 64;  // two waves per SIMD: a tile is a chain of dependent global round trips
-
-// Record range of every BUCKET = tile id & 4095 (tile id = key >> shift): the records are partitioned by the low 12 bits of
-// the tile id in ONE stable pass whatever the number of touched blocks; up to 255 touched blocks a bucket is a tile, beyond
-// that the tiles b, b + 4096, ... share bucket b and the apply takes them in turn.  (Invalid keys fall into bucket 4095 and
-// are skipped there.)  mask == 0xFFFFFFFF: the key is the tile id itself (piece path), invalid keys have no range.
-__global__ void __launch_bounds__(256) k_block_starts(RecordView V, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, const Counters* cnt, u32 shift, u32 mask) {
-  const u32 n = (cnt->err & kErrRecords) ? 0u : *V.d_n;
-  const u32* __restrict__ key = V.key[V.info->parity & 1u];
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 k = key[i];
-    if (mask == 0xFFFFFFFFu && k == kInvalid) continue;
-    const u32 t = (k >> shift) & mask;
-    if (i == 0 || ((key[i - 1] >> shift) & mask) != t) tile_beg[t] = i;
-    if (i + 1 == n || ((key[i + 1] >> shift) & mask) != t) tile_end[t] = i + 1;
-  }
-}
-
-// Flush of a batch of `fill` hard records (block-wide; every thread calls it): sort the batch by voxel in LDS (stable
-// counting sort: per-voxel counts, exclusive scan, wave match-any ranks, waves in turn), then every voxel replays its run
-// in order with the reference's updateTsdfVoxel.  acc_cnt / acc_sum are scratch here (phases 1-2 are over).
-template <u32 kT, u32 kTS>
-__device__ __forceinline__ void tile_flush(const FrameParams& P, u32* blk, u32* acc_cnt, u32* acc_sum, const unsigned short* b_lin, const float* b_sdf,
-                                           const float* b_uw, const u32* b_col, unsigned short* perm, u32* scan_lds, u32 fill, u32 tid, u32 lane, u32 wave) {
-  constexpr u32 kTV = 1u << kTS;  // voxels per tile
-  static_assert(kTV <= kT, "thread = voxel");
-  if (tid < kTV) acc_cnt[tid] = 0;
-  __syncthreads();
-  for (u32 p = tid; p < fill; p += kT) atomicAdd(&acc_cnt[b_lin[p] & (kTV - 1u)], 1u);
-  __syncthreads();
-  {  // exclusive scan over the tile's voxels (thread = voxel)
-    const u32 c = (tid < kTV) ? acc_cnt[tid] : 0u;
-    u32 tot;
-    const u32 ex = block_exclusive_scan<kT / 64>(c, &tot, scan_lds);
-    if (tid < kTV) acc_sum[tid] = ex;
-  }
-  __syncthreads();
-  const u32 chunk = ((fill + kT - 1u) / kT) * 64u;  // positions per wave, a multiple of 64
-  for (u32 w = 0; w < kT / 64; ++w) {
-    if (wave == w) {
-      const u32 wbeg = min(fill, w * chunk), wend = min(fill, wbeg + chunk);
-      for (u32 p0 = wbeg; p0 < wend; p0 += 64) {
-        const u32 p = p0 + lane;
-        const bool valid = p < wend;
-        const u32 lin = valid ? (b_lin[p] & (kTV - 1u)) : 0u;
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (u32 b = 0; b < kTS; ++b) {
-          const bool bit = (lin >> b) & 1u;
-          const u64 m = __ballot(bit);
-          peers &= bit ? m : ~m;
-        }
-        const u64 lower = peers & ((1ull << lane) - 1ull);
-        if (valid) perm[acc_sum[lin] + static_cast<u32>(__popcll(lower))] = static_cast<unsigned short>(p);
-        wave_lds_handover();
-        if (valid && lower == 0ull) acc_sum[lin] += static_cast<u32>(__popcll(peers));
-        wave_lds_handover();
-      }
-    }
-    __syncthreads();
-  }
-  {
-    const u32 v = tid & (kTV - 1u);
-    const u32 c = (tid < kTV) ? acc_cnt[v] : 0u;
-    if (c) {
-      const u32 e = acc_sum[v];
-      Voxel vx{__uint_as_float(blk[3 * v]), __uint_as_float(blk[3 * v + 1]), blk[3 * v + 2]};
-      for (u32 j = e - c; j < e; ++j) {
-        const u32 idx = perm[j];
-        const float uw = b_uw[idx];
-        // a saturating record on a voxel that sits at +truncation only adds its weight: exactly what updateTsdfVoxel
-        // computes there (distance provably stays == truncation -- saturating_update -- and the weight is the same
-        // float addition), without its divisions: most records of a dirty voxel's run
-        if ((b_lin[idx] & 0x8000u) && vx.d == P.trunc)
-          vx.w = std_min(P.max_weight, vx.w + uw);
-        else
-          update_voxel(P, vx, b_sdf[idx], uw, b_col[idx]);
-      }
-      blk[3 * v] = __float_as_uint(vx.d);
-      blk[3 * v + 1] = __float_as_uint(vx.w);
-      blk[3 * v + 2] = vx.c;
-    }
-  }
-  __syncthreads();
-}
-
-// compute_sdf with the ray's part (dv = point_G - origin, dist = |dv|) taken from RayArrays::q: the same operations on the same values
-__device__ __forceinline__ float step_sdf(const FrameParams& P, F3 dv, float dist, int gx, int gy, int gz) {
-  const F3 origin{P.tx, P.ty, P.tz};
-  const F3 c{center_coord(gx, P.voxel_size), center_coord(gy, P.voxel_size), center_coord(gz, P.voxel_size)};
-  const F3 v = c - origin;
-  const float proj = dot3(v, dv) / dist;
-  return dist - proj;
-}
-
-// what a record needs from its ray.  kQ (merged): one 32-B line written by the merge -- point_G - origin, its length, the
-// weight -- instead of four 4-B gathers from four arrays; the ray gathers were a quarter of this kernel at 1 cm with one
-// frame in flight and 40 % of it beside the other stages (ablation: DESIGN.md section 6)
-struct RayOfRecord {
-  F3 a;      // kQ: point_G - origin; else point_G
-  float dist, w;
-};
-template <bool kQ>
-__device__ __forceinline__ RayOfRecord ray_of_record(const RayArrays& R, u32 r) {
-  if constexpr (kQ) {
-    typedef float F4 __attribute__((ext_vector_type(4)));
-    const F4* q = reinterpret_cast<const F4*>(R.q + static_cast<size_t>(r) * 8u);
-    const F4 q0 = q[0];
-    return RayOfRecord{F3{q0.x, q0.y, q0.z}, q0.w, q[1].x};
-  } else {
-    return RayOfRecord{F3{R.px[r], R.py[r], R.pz[r]}, 0.0f, R.w[r]};
-  }
-}
-template <bool kQ>
-__device__ __forceinline__ float sdf_of_record(const FrameParams& P, const RayOfRecord& y, int gx, int gy, int gz) {
-  if constexpr (kQ)
-    return step_sdf(P, y.a, y.dist, gx, gy, gz);
-  else
-    return compute_sdf(P, y.a, gx, gy, gz);
-}
-
-template <bool kQ, u32 kTS, bool kBucket>
-__global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
-                                                     u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
-  // kTS = log2(voxels per tile): 8 = one z slab of the block (16 tiles per block), 9 = two (fine voxels: half as many tiles,
-  // each a chain of dependent round trips, and thread = voxel uses all 512 threads)
-  constexpr u32 kTV = 1u << kTS, kTPB = 4096u >> kTS, kSlabs = kTV / 256u;
-  const FrameParams P = *Pp;
-  __shared__ u32 blk[kTV * kWordsPerVoxel];
-  __shared__ u32 acc_sum[kTV];  // phases 1-2: sum of the saturating weights of a voxel; phase 3: end of the voxel's run in the sorted batch
-  __shared__ u32 acc_cnt[kTV];  // phases 1-2: records of the voxel | dirty << 31; phase 3: records of the voxel in the batch
-  __shared__ u32 hardbits[kTV / 32];
-  __shared__ float b_sdf[kHardBatch], b_uw[kHardBatch];
-  __shared__ u32 b_col[kHardBatch];
-  __shared__ unsigned short b_lin[kHardBatch], perm[kHardBatch];
-  __shared__ u32 wsum[kBW], scan_lds[kBW], any_hard_s, any_rec_s;
-  // last kernel of the frame: make this frame's error bits sticky until the host next looks, and leave the layer's block
-  // count where the host can read it without a sync (pinned word; it decides when to grow the pool)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (cnt->err) atomicOr(layer_err, cnt->err);
-    *h_nblocks = min(*L.d_nblocks, L.capacity);
-  }
-  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTPB;
-  const u32 par = V.info->parity & 1u;
-  const u32* __restrict__ rec_key = V.key[par];
-  const u32* __restrict__ rec_ray = V.ray[par];
-  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const bool exact_cap = P.max_weight <= 16711680.0f;  // 2^24 - 2^16: w + u never leaves the exact integers before the cap applies
-  u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
-  // kBucket (records partitioned in one pass by tile id & 4095): a unit is a bucket; the tiles unit, unit + 4096, ... share its
-  // record range and are taken in turn, each looking at its own records only.  Otherwise a unit is a tile.
-  const u32 n_units = kBucket ? min(n_tiles, 4096u) : n_tiles;
-  for (u32 unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-    const u32 beg = tile_beg[unit], end = tile_end[unit];
-    if (end <= beg) continue;  // (uniform) no record touches this slab of the block
-   for (u32 tile = unit; tile < n_tiles; tile += (kBucket ? 4096u : n_tiles)) {
-    __syncthreads();           // everybody has read its range and is done with the previous tile's LDS
-    if (tid == 0) {
-      tile_beg[unit] = 0;  // leave the tables empty for the next frame
-      tile_end[unit] = 0;
-      any_hard_s = 0;
-      any_rec_s = 0;
-    }
-    const int4 info = ord_info[tile / kTPB];
-    const u32 pool = static_cast<u32>(info.w);
-    if (pool == kInvalid) continue;  // (uniform; such a block's records carry invalid keys anyway)
-    const int gz0 = info.z + static_cast<int>((tile & (kTPB - 1u)) * kSlabs);  // first z slab of the tile
-    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTPB - 1u)) * kTV) * kWordsPerVoxel;
-    for (u32 i = tid; i < kTV * kWordsPerVoxel; i += kBT) blk[i] = gblk[i];
-    for (u32 v = tid; v < kTV; v += kBT) {
-      acc_sum[v] = 0;
-      acc_cnt[v] = 0;
-    }
-    __syncthreads();
-    // ---- 1. classify --------------------------------------------------------------------------------------------------
-    for (u32 i0 = beg + tid; i0 < end; i0 += 2 * kBT) {  // two records per thread in flight: the gathers are latency-bound
-      const u32 i1 = i0 + kBT;
-      const bool has1 = i1 < end;
-      const u32 k0 = rec_key[i0], r0 = rec_ray[i0];
-      const u32 k1 = has1 ? rec_key[i1] : 0u, r1 = has1 ? rec_ray[i1] : r0;
-      const RayOfRecord y0 = ray_of_record<kQ>(R, r0), y1 = ray_of_record<kQ>(R, r1);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 1 && !has1) break;
-        if (kBucket && ((u ? k1 : k0) >> kTS) != tile) continue;  // another tile of the bucket (or an invalid key)
-        const u32 lin = (u ? k1 : k0) & (kTV - 1u);
-        const RayOfRecord& y = u ? y1 : y0;
-        const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), gz0 + static_cast<int>(lin >> 8));
-        const float uw = update_weight(P, sdf, y.w);
-        bool fold = foldable_update(P, sdf, uw);
-        if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
-        atomicAdd(&acc_cnt[lin], 1u);
-        if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
-      }
-    }
-    __syncthreads();
-    // ---- 2. fold what folds (thread = voxel) ----------------------------------------------------------------------------
-    {
-      const u32 v = tid & (kTV - 1u);
-      const u32 c = (tid < kTV) ? acc_cnt[v] : 0u, count = c & 0x7FFFFFFFu;
-      bool hard = false;
-      if (count) {
-        my_updates += count;
-        my_voxels += 1;
-        my_maxrun = max(my_maxrun, count);
-        const float d = __uint_as_float(blk[3 * v]), w = __uint_as_float(blk[3 * v + 1]);
-        const u32 sum = acc_sum[v];
-        hard = true;
-        if (!(c >> 31) && sum < (1u << 30) && (w == 0.0f || d == P.trunc)) {
-          if (w >= P.max_weight) {
-            hard = false;  // min(max_weight, w + u) == max_weight for every u > 0: nothing changes
-          } else if (w == truncf(w) && w >= 0.0f) {
-            const unsigned long long total = static_cast<unsigned long long>(w) + sum;
-            if (total < 16777216ull || exact_cap) {
-              const float ft = static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u);
-              blk[3 * v] = __float_as_uint(P.trunc);  // an unobserved voxel's first saturating update sets the distance to +truncation
-              blk[3 * v + 1] = __float_as_uint(ft >= P.max_weight ? P.max_weight : ft);
-              hard = false;
-            }
-          }
-        }
-      }
-      const u64 hm = __ballot(hard);
-      if (lane == 0 && tid < kTV) {
-        hardbits[wave * 2] = static_cast<u32>(hm);
-        hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
-        if (hm) any_hard_s = 1;
-      }
-      if (kBucket && count) any_rec_s = 1;  // (same value from every writer)
-    }
-    __syncthreads();
-    if (kBucket && !any_rec_s) continue;  // (uniform) a tile of the bucket without records of its own in this slab: nothing to write
-    // ---- 3. the hard voxels: ordered replay ---------------------------------------------------------------------------
-    if (any_hard_s) {
-      u32 fill = 0;
-      for (u32 base = beg;; base += kBT) {
-        const bool done = base >= end;
-        if (done || fill + kBT > kHardBatch) {
-          // -- flush: sort the batch by voxel (stable), replay every voxel's run in order
-          if (fill) {
-            tile_flush<kBT, kTS>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
-            fill = 0;
-          }
-          if (done) break;
-        }
-        // -- one round: kBT consecutive records, the hard ones appended to the batch in order
-        const u32 i = base + tid;
-        bool keep = false;
-        u32 lin = 0;
-        if (i < end) {
-          const u32 k = rec_key[i];
-          lin = k & (kTV - 1u);
-          keep = (!kBucket || (k >> kTS) == tile) && ((hardbits[lin >> 5] >> (lin & 31u)) & 1u);
-        }
-        const u64 m = __ballot(keep);
-        if (lane == 0) wsum[wave] = static_cast<u32>(__popcll(m));
-        __syncthreads();
-        u32 pos = fill + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
-        for (u32 w = 0; w < wave; ++w) pos += wsum[w];
-        if (keep) {
-          const u32 r = rec_ray[i];
-          const RayOfRecord y = ray_of_record<kQ>(R, r);
-          const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>((lin >> 4) & 15u), gz0 + static_cast<int>(lin >> 8));
-          const float uw = update_weight(P, sdf, y.w);
-          b_lin[pos] = static_cast<unsigned short>(lin | (foldable_update(P, sdf, uw) ? 0x8000u : 0u));
-          b_sdf[pos] = sdf;
-          b_uw[pos] = uw;
-          b_col[pos] = R.color[r];
-        }
-#pragma unroll
-        for (u32 w = 0; w < kBW; ++w) fill += wsum[w];
-        __syncthreads();
-      }
-    }
-    // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
-    __syncthreads();
-    for (u32 i = tid; i < kTV * kWordsPerVoxel; i += kBT) gblk[i] = blk[i];
-   }
-  }
-  // statistics
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    my_updates += __shfl_xor(my_updates, off, 64);
-    my_voxels += __shfl_xor(my_voxels, off, 64);
-    my_maxrun = max(my_maxrun, static_cast<u32>(__shfl_xor(static_cast<int>(my_maxrun), off, 64)));
-  }
-  if (lane == 0 && my_voxels) {
-    u32* sh = cnt->shard[(blockIdx.x * kBW + wave) & 63u];
-    atomicAdd(&sh[kShUpdates], my_updates);
-    atomicAdd(&sh[kShVoxels], my_voxels);
-    atomicMax(&sh[kShMaxRun], my_maxrun);
-  }
-}
-
-// ---- piece apply: k_apply_block's four phases, the tile's steps gathered through its pieces ------------------------------------
-// The pieces arrive sorted by tile, ray order inside a tile preserved (stable sort of slots that were laid out in ray order).
-// A round takes up to 256 pieces, thread = piece: header (slot, ray, length), the piece's bytes with one or two 16-B loads,
-// the ray once per piece -- a step costs one byte of HBM traffic instead of an 8-B record.  The round is then EXPANDED in LDS
-// into its steps (exclusive scan of the lengths; step -> voxel byte, piece), in (piece, step) = ray order, and phases 1 and
-// 3 run over the steps with one lane per step exactly like k_apply_block runs over records.  A tile of at most 256 pieces
-// (nearly all of them at fine voxels) is expanded once; the next tile's range is fetched while this one is worked on.
-constexpr u32 kPT = 256, kPW = kPT / 64;
-constexpr u32 kPieceBatch = 768;
-constexpr u32 kStepCap = kPT * 31;  // steps of one round
-struct PieceView {
-  const u32* key[2];
-  const u32* start[2];
-  const u32* raylen[2];
-  const SortInfo* info;
-};
-typedef u32 U32x4 __attribute__((ext_vector_type(4)));
-
-// f(j, lin) for every step j < len of this lane's piece, lanes in lockstep (j is wave-uniform; every lane of the wave must call)
-template <typename F>
-__device__ __forceinline__ void piece_for_each(u32 len, const u64 (&H)[4], F&& f) {
-#pragma unroll
-  for (u32 h = 0; h < 4; ++h) {
-    if (__ballot(8u * h < len) == 0ull) break;
-    u64 cur = H[h];
-#pragma unroll 1
-    for (u32 b = 0; b < 8; ++b) {
-      const u32 j = 8u * h + b;
-      const bool on = j < len;
-      if (__ballot(on) == 0ull) break;
-      const u32 lin = static_cast<u32>(cur) & 255u;
-      cur >>= 8;
-      if (on) f(j, lin);
-    }
-  }
-}
-
-__global__ void __launch_bounds__(kPT) k_apply_pieces(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, PieceView V,
-                                                      const uint8_t* __restrict__ lin8, u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt,
-                                                      u32* layer_err, u32* __restrict__ h_nblocks) {
-  const FrameParams P = *Pp;
-  __shared__ u32 blk[kTileVox * kWordsPerVoxel];
-  __shared__ u32 acc_sum[kTileVox];
-  __shared__ u32 acc_cnt[kTileVox];
-  __shared__ u32 hardbits[kTileVox / 32];
-  __shared__ uint8_t s_lin[kStepCap], s_pc[kStepCap];             // the round's steps: voxel byte, piece (= thread that loaded it)
-  __shared__ float pr_x[kPT], pr_y[kPT], pr_z[kPT], pr_d[kPT], pr_w[kPT];  // the round's pieces: point_G - origin, its length, the ray's weight
-  __shared__ u32 pr_ray[kPT];
-  __shared__ float b_sdf[kPieceBatch], b_uw[kPieceBatch];
-  __shared__ u32 b_col[kPieceBatch];
-  __shared__ unsigned short b_lin[kPieceBatch], perm[kPieceBatch];
-  __shared__ u32 wsum[kPW], scan_lds[kPW], any_hard_s;
-  static_assert(kPT == kTileVox, "phase 2 and the flush use thread = voxel");
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // last kernel of the frame (see k_apply_block)
-    if (cnt->err) atomicOr(layer_err, cnt->err);
-    *h_nblocks = min(*L.d_nblocks, L.capacity);
-  }
-  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTilesPerBlock;
-  const u32 par = V.info->parity & 1u;
-  const u32* __restrict__ p_start = V.start[par];
-  const u32* __restrict__ p_raylen = V.raylen[par];
-  const U32x4* __restrict__ lin128 = reinterpret_cast<const U32x4*>(lin8);
-  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const bool exact_cap = P.max_weight <= 16711680.0f;
-  u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
-  u32 tile = blockIdx.x;
-  u32 nbeg = 0, nend = 0;
-  int4 ninfo = make_int4(0, 0, 0, 0);
-  if (tile < n_tiles) {
-    nbeg = tile_beg[tile];
-    nend = tile_end[tile];
-    ninfo = ord_info[tile >> kSlabBits];
-  }
-  for (; tile < n_tiles; tile += gridDim.x) {
-    const u32 beg = nbeg, end = nend;
-    const int4 info = ninfo;
-    if (tile + gridDim.x < n_tiles) {  // the next tile's range: in flight while this tile is worked on
-      nbeg = tile_beg[tile + gridDim.x];
-      nend = tile_end[tile + gridDim.x];
-      ninfo = ord_info[(tile + gridDim.x) >> kSlabBits];
-    }
-    if (end <= beg) continue;  // (uniform) no piece in this slab of the block
-    __syncthreads();           // everybody has read the range and is done with the previous tile's LDS
-    if (tid == 0) {
-      tile_beg[tile] = 0;  // leave the tables empty for the next frame
-      tile_end[tile] = 0;
-      any_hard_s = 0;
-    }
-    const u32 pool = static_cast<u32>(info.w);
-    if (pool == kInvalid) continue;  // (uniform; such a block's pieces carry invalid keys anyway)
-    const int gz = info.z + static_cast<int>(tile & (kTilesPerBlock - 1u));
-    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTilesPerBlock - 1u)) * kTileVox) * kWordsPerVoxel;
-    // expand the round of pieces [pb, pb + kPT) into s_lin / s_pc / pr_*; returns its number of steps (block-wide)
-    auto expand_round = [&](u32 pb) -> u32 {
-      const u32 pi = pb + tid;
-      u32 len = 0;
-      u64 H[4] = {0, 0, 0, 0};
-      if (pi < end) {
-        const u32 st = p_start[pi], rl = p_raylen[pi];
-        const u32 r = rl >> kPieceLenBits;
-        len = rl & ((1u << kPieceLenBits) - 1u);
-        const U32x4 a = lin128[static_cast<size_t>(st) * 2u];
-        U32x4 b = {0, 0, 0, 0};
-        if (len > 16u) b = lin128[static_cast<size_t>(st) * 2u + 1u];
-        typedef float F4 __attribute__((ext_vector_type(4)));
-        const F4* q = reinterpret_cast<const F4*>(R.q + static_cast<size_t>(r) * 8u);
-        const F4 q0 = q[0];
-        pr_w[tid] = q[1].x;
-        pr_x[tid] = q0.x;
-        pr_y[tid] = q0.y;
-        pr_z[tid] = q0.z;
-        pr_d[tid] = q0.w;
-        pr_ray[tid] = r;
-        H[0] = a.x | (static_cast<u64>(a.y) << 32);
-        H[1] = a.z | (static_cast<u64>(a.w) << 32);
-        H[2] = b.x | (static_cast<u64>(b.y) << 32);
-        H[3] = b.z | (static_cast<u64>(b.w) << 32);
-      }
-      u32 tot;
-      const u32 off = block_exclusive_scan<kPW>(len, &tot, scan_lds);
-      piece_for_each(len, H, [&](u32 j, u32 lin) {
-        s_lin[off + j] = static_cast<uint8_t>(lin);
-        s_pc[off + j] = static_cast<uint8_t>(tid);
-      });
-      __syncthreads();
-      return tot;
-    };
-    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kPT) blk[i] = gblk[i];
-    acc_sum[tid] = 0;
-    acc_cnt[tid] = 0;
-    const bool keeps = end - beg <= kPT;  // one round: its expansion serves phase 3 too
-    u32 T = 0;
-    // ---- 1. classify (lane = step) ------------------------------------------------------------------------------------
-    for (u32 pb = beg; pb < end; pb += kPT) {
-      if (pb != beg) __syncthreads();  // the previous round's steps have been consumed
-      T = expand_round(pb);            // (its barrier also covers blk / acc_*)
-      for (u32 s0 = tid; s0 < T; s0 += kPT) {
-        const u32 lin = s_lin[s0], pc = s_pc[s0];
-        const float sdf = step_sdf(P, F3{pr_x[pc], pr_y[pc], pr_z[pc]}, pr_d[pc], info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
-        const float uw = update_weight(P, sdf, pr_w[pc]);
-        bool fold = foldable_update(P, sdf, uw);
-        if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
-        atomicAdd(&acc_cnt[lin], 1u);
-        if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
-      }
-    }
-    __syncthreads();
-    // ---- 2. fold what folds (thread = voxel) ----------------------------------------------------------------------------
-    {
-      const u32 v = tid;
-      const u32 c = acc_cnt[v], count = c & 0x7FFFFFFFu;
-      bool hard = false;
-      if (count) {
-        my_updates += count;
-        my_voxels += 1;
-        my_maxrun = max(my_maxrun, count);
-        const float d = __uint_as_float(blk[3 * v]), w = __uint_as_float(blk[3 * v + 1]);
-        const u32 sum = acc_sum[v];
-        hard = true;
-        if (!(c >> 31) && sum < (1u << 30) && (w == 0.0f || d == P.trunc)) {
-          if (w >= P.max_weight) {
-            hard = false;  // min(max_weight, w + u) == max_weight for every u > 0: nothing changes
-          } else if (w == truncf(w) && w >= 0.0f) {
-            const unsigned long long total = static_cast<unsigned long long>(w) + sum;
-            if (total < 16777216ull || exact_cap) {
-              const float ft = static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u);
-              blk[3 * v] = __float_as_uint(P.trunc);
-              blk[3 * v + 1] = __float_as_uint(ft >= P.max_weight ? P.max_weight : ft);
-              hard = false;
-            }
-          }
-        }
-      }
-      const u64 hm = __ballot(hard);
-      if (lane == 0) {
-        hardbits[wave * 2] = static_cast<u32>(hm);
-        hardbits[wave * 2 + 1] = static_cast<u32>(hm >> 32);
-        if (hm) any_hard_s = 1;
-      }
-    }
-    __syncthreads();
-    // ---- 3. the hard voxels: ordered replay (lane = step, chunks of kPT steps in ray order) ---------------------------
-    if (any_hard_s) {
-      u32 fill = 0;
-      for (u32 pb = beg; pb < end; pb += kPT) {
-        if (!keeps) {
-          __syncthreads();
-          T = expand_round(pb);
-        }
-        for (u32 base = 0; base < T; base += kPT) {
-          if (fill + kPT > kPieceBatch) {
-            tile_flush<kPT, kTileShift>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
-            fill = 0;
-          }
-          const u32 s0 = base + tid;
-          bool keep = false;
-          u32 lin = 0;
-          if (s0 < T) {
-            lin = s_lin[s0];
-            keep = (hardbits[lin >> 5] >> (lin & 31u)) & 1u;
-          }
-          const u64 m = __ballot(keep);
-          if (lane == 0) wsum[wave] = static_cast<u32>(__popcll(m));
-          __syncthreads();
-          u32 pos = fill + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
-          for (u32 w = 0; w < wave; ++w) pos += wsum[w];
-          if (keep) {
-            const u32 pc = s_pc[s0];
-            const float sdf = step_sdf(P, F3{pr_x[pc], pr_y[pc], pr_z[pc]}, pr_d[pc], info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
-            const float uw = update_weight(P, sdf, pr_w[pc]);
-            b_lin[pos] = static_cast<unsigned short>(lin | (foldable_update(P, sdf, uw) ? 0x8000u : 0u));
-            b_sdf[pos] = sdf;
-            b_uw[pos] = uw;
-            b_col[pos] = R.color[pr_ray[pc]];
-          }
-#pragma unroll
-          for (u32 w = 0; w < kPW; ++w) fill += wsum[w];
-          __syncthreads();
-        }
-      }
-      if (fill) tile_flush<kPT, kTileShift>(P, blk, acc_cnt, acc_sum, b_lin, b_sdf, b_uw, b_col, perm, scan_lds, fill, tid, lane, wave);
-    }
-    // ---- 4. the tile goes back ----------------------------------------------------------------------------------------
-    __syncthreads();
-    for (u32 i = tid; i < kTileVox * kWordsPerVoxel; i += kPT) gblk[i] = blk[i];
-  }
-  // statistics
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    my_updates += __shfl_xor(my_updates, off, 64);
-    my_voxels += __shfl_xor(my_voxels, off, 64);
-    my_maxrun = max(my_maxrun, static_cast<u32>(__shfl_xor(static_cast<int>(my_maxrun), off, 64)));
-  }
-  if (lane == 0 && my_voxels) {
-    u32* sh = cnt->shard[(blockIdx.x * kPW + wave) & 63u];
-    atomicAdd(&sh[kShUpdates], my_updates);
-    atomicAdd(&sh[kShVoxels], my_voxels);
-    atomicMax(&sh[kShMaxRun], my_maxrun);
-  }
-}
+#include "cox_apply_records.hpp"
+#include "cox_apply_tile.hpp"
 
 // ---- depth front end ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_depth_flags(const float* __restrict__ depth, u32 n, u32* __restrict__ flag) {
