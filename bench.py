@@ -42,7 +42,8 @@ KERNELS_OF_CLASS = {
     "merge": "k_bundle_merge", "apply": "k_block_starts+k_apply_block", "bundle_hash": "fillBuffer+k_bundle_insert+k_bundle_keys+k_bundle_clear",
     "point_sort": "k_rs_hist/offsets/scatter<11> (points)", "touch_emit": "k_scan_small+k_touch*+k_emit*",
     "record_sort": "k_rs_hist/offsets/scatter<12> (records)", "fast_start": "k_fast_points..k_fast_rays (+ point sort)",
-    "fast_visits": "k_fast_visits+visit sort+k_fast_inverse", "fast_sweeps": "k_fast_scan_tiles+k_fast_sweep (all sweeps of a frame)",
+    "fast_visits": "k_fast_visits+visit sort+k_fast_inverse (round 0: 8 candidate steps per ray)", "fast_sweeps": "k_fast_sweep (round 0's relaxation launches)",
+    "fast_round1": "k_fast_grow+scan+k_fast_visits+visit sort+k_fast_inverse+k_fast_sweep (round 1: whole walks of the rays that got through)",
 }
 
 

@@ -258,6 +258,15 @@ class Integrator:
         self.eng.check(self.eng.fn("integrate_points_dev")(self.h, _fp(T), C.c_void_p(xyz_ptr), C.c_void_p(rgba_ptr or 0),
                                                            C.c_uint64(n), C.c_int(int(freespace))), "integrate_points_dev")
 
+    def integrate_points_async(self, T_G_C, xyz_ptr, rgba_ptr, n, freespace=False):
+        """Host buffers (addresses), frame not waited for; pinned buffers must stay untouched until wait_inputs() / sync()."""
+        T = np.ascontiguousarray(T_G_C, np.float32)
+        self.eng.check(self.eng.fn("integrate_points_async")(self.h, _fp(T), C.c_void_p(xyz_ptr), C.c_void_p(rgba_ptr or 0),
+                                                             C.c_uint64(n), C.c_int(int(freespace))), "integrate_points_async")
+
+    def wait_inputs(self):
+        self.eng.check(self.eng.fn("integrator_wait_inputs")(self.h), "integrator_wait_inputs")
+
     def integrate_depth_dev(self, T_G_C, depth_ptr, rgba_ptr, w, h, K):
         T = np.ascontiguousarray(T_G_C, np.float32)
         K = np.ascontiguousarray(K, np.float32)
@@ -286,7 +295,7 @@ class Integrator:
         self.eng.check(self.eng.fn("integrator_stage_times")(self.h, ms, n, C.c_int(int(reset))), "integrator_stage_times")
         return {"merge": (float(ms[0]), int(n[0])), "apply": (float(ms[1]), int(n[1]))}
 
-    KERNEL_CLASSES = ("merge", "apply", "bundle_hash", "point_sort", "touch_emit", "record_sort", "fast_start", "fast_visits", "fast_sweeps")
+    KERNEL_CLASSES = ("merge", "apply", "bundle_hash", "point_sort", "touch_emit", "record_sort", "fast_start", "fast_visits", "fast_sweeps", "fast_round1")
 
     def class_times(self, reset=False):
         """{class: (ms, regions)} for every kernel class of a frame (cox_kernel_class), HIP events on the kernels' own streams."""
@@ -294,6 +303,13 @@ class Integrator:
         ms, n = (C.c_double * k)(), (C.c_uint64 * k)()
         self.eng.check(self.eng.fn("integrator_class_times")(self.h, ms, n, C.c_int(int(reset))), "integrator_class_times")
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(self.KERNEL_CLASSES)}
+
+    def fast_stats(self):
+        """method 'fast': run totals of the observed-set relaxation (cox_integrator_fast_stats)."""
+        out = (C.c_uint64 * 7)()
+        self.eng.check(self.eng.fn("integrator_fast_stats")(self.h, out), "integrator_fast_stats")
+        return dict(sequential_frames=int(out[0]), round1_frames=int(out[1]), passes_round0=int(out[2]), passes_round1=int(out[3]),
+                    frames=int(out[4]), sequential_frames_list_outgrown=int(out[5]), sequential_frames_barrier_gave_up=int(out[6]))
 
     def host_time(self, reset=False):
         """(ms, frames): host time spent inside the integrate calls (enqueueing; cox_integrator_host_time)."""

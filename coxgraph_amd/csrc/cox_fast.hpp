@@ -95,8 +95,17 @@ __global__ void __launch_bounds__(256) k_fast_start_commit(const FrameParams* __
 }
 // thread = sequence number: the points that start a ray, compacted in visiting order (ray id = rank among them)
 __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict__ Pp, const u32* __restrict__ fresh, const u32* __restrict__ rank, RayArrays R,
-                                                   u32* __restrict__ cap, u32 cap0, Counters* cnt) {
+                                                   u32* __restrict__ cap, u32* __restrict__ reach, u32 cap0, u32 vcap0, Counters* cnt) {
   const FrameParams P = *Pp;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // round 0: cap0 list slots per ray at a fixed stride (no scan)
+    const u64 nv = static_cast<u64>(cnt->n_rays) * cap0;
+    if (nv > vcap0) {  // (more rays than list slots: only beyond 2^32 / cap0 points; the sequential kernel takes the frame)
+      cnt->fast.n_visits[0] = 0u;
+      cnt->fast.overflow = 2u;
+    } else {
+      cnt->fast.n_visits[0] = static_cast<u32>(nv);
+    }
+  }
   for (u32 seq = blockIdx.x * blockDim.x + threadIdx.x; seq < P.n_points; seq += gridDim.x * blockDim.x) {
     if (!fresh[seq]) continue;
     const u32 r = rank[seq];
@@ -115,41 +124,45 @@ __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict
     R.color[r] = pack_rgba_wire(P.rgba, idx);
     R.flags[r] = 1u | (clearing ? 2u : 0u);
     R.nsteps[r] = d.nsteps;  // the whole walk; replaced by the ray's reach once that is known
-    cap[r] = min(d.nsteps, cap0);  // candidate visits are generated for the first cap[r] steps (k_fast_grow_caps)
+    const u32 c = min(d.nsteps, cap0);
+    cap[r] = c;    // candidate visits are generated for the first cap[r] steps (k_fast_grow gives a ray its whole walk)
+    reach[r] = c;  // first guess: nobody stops
   }
 }
 
 // ---- observed set -------------------------------------------------------------------------------------------------
-// wave = ray: every voxel the ray would visit if nothing stopped it, in walking order (parallel DDA of the merged
-// integrator's bundles, wave_ray_path; sequential on lane 0 for the rays that one does not cover)
+// wave = ray: the first cap[r] voxels the ray would visit if nothing stopped it, in walking order (parallel DDA of the merged
+// integrator's bundles, wave_ray_path; sequential on lane 0 for the rays that one does not cover).
+// Round 0 (stride > 0): ray r owns the list slots [r * stride, (r + 1) * stride); slots past the end of a short walk get the
+// key kFastSlots, which sorts behind every slot.  Round 1 (stride == 0): lists at voff[r] (scan of the grown caps), only when
+// round 0 grew something.
 template <u32 kAxisCap>
 __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ vhash, u32* __restrict__ vkey,
-                                                     u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ reach, const u32* __restrict__ cap, int init_reach, u32 vcap,
-                                                     Counters* cnt) {
+                                                     u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ voff, const u32* __restrict__ cap, u32 stride,
+                                                     u32 vcap, Counters* cnt) {
   const FrameParams P = *Pp;
   __shared__ float lds_t[4][3 * kAxisCap];
   __shared__ u32 lds_path[4][3 * kAxisCap];
+  if (uniform_u32(cnt->fast.overflow) != 0u) return;  // lists that do not fit: the sequential kernel takes the frame
+  if (stride == 0 && uniform_u32(cnt->fast.grew) == 0u) return;
   const u32 n_rays = uniform_u32(cnt->n_rays);
-  const bool overflow = uniform_u32(cnt->n_records) > vcap;  // cannot happen unless the worst-case bound itself exceeds the 2^31 limit
-  if (overflow && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, kErrRecords);
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
   float* tl = lds_t[wave];
   u32* path = lds_path[wave];
   const u32 waves_total = (gridDim.x * blockDim.x) >> 6;
   for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_rays; r += waves_total) {
-    if (overflow) {  // the frame is dropped as a whole
-      if (lane == 0) {
-        R.nsteps[r] = 0;
-        reach[r] = 0;
-      }
-      continue;
-    }
     const u32 nfull = uniform_u32(R.nsteps[r]);
     const u32 ns = uniform_u32(cap[r]);  // <= nfull
-    if (lane == 0 && init_reach) reach[r] = ns;
+    const u32 off = stride ? r * stride : uniform_u32(voff[r]);
+    if (stride) {
+      if (lane == 0) voff[r] = off;
+      for (u32 s = ns + lane; s < stride; s += 64) {
+        vkey[off + s] = kFastSlots;
+        vval[off + s] = off + s;
+      }
+    }
     if (ns == 0) continue;
-    const u32 off = uniform_u32(R.rec_off[r]);
     const F3 pg{readlane_f32(R.px[r], 0), readlane_f32(R.py[r], 0), readlane_f32(R.pz[r], 0)};
     Dda d;
     dda_setup(d, P, pg, (uniform_u32(R.flags[r]) & 2u) != 0);
@@ -179,195 +192,393 @@ __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restri
   }
 }
 
-// visits of the frame (0 when the frame was dropped for overflowing the visit buffers)
-__device__ __forceinline__ u32 fast_num_visits(const Counters* cnt, u32 vcap) { return cnt->n_records > vcap ? 0u : cnt->n_records; }
-// the visits in slot-sorted order: where each visit went (pos_of), and per sorted position its ray, its step on that
-// ray and its hash (so the sweeps read coalesced arrays instead of chasing visit -> ray -> offset)
-__global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ vval_sorted, const u32* __restrict__ vray, const u64* __restrict__ vhash,
-                                                      const u32* __restrict__ voff, u32* __restrict__ pos_of, u32* __restrict__ sray, u32* __restrict__ sstep,
-                                                      u64* __restrict__ shash, const Counters* cnt, u32 vcap) {
-  const u32 n = fast_num_visits(cnt, vcap);
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 v = vval_sorted[i];
-    const u32 r = vray[v];
-    pos_of[v] = i;
-    sray[i] = r;
-    sstep[i] = v - voff[r];
-    shash[i] = vhash[v];
-  }
-}
-
-template <int NW>
-__device__ __forceinline__ u32 block_exclusive_max(u32 v, u32* total, u32* lds /*[NW]*/) {
-  const u32 lane = lane_id();
-  const u32 wave = threadIdx.x >> 6;
-  u32 inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const u32 o = static_cast<u32>(__shfl_up(static_cast<int>(inc), off, 64));
-    if (lane >= static_cast<u32>(off)) inc = max(inc, o);
-  }
-  u32 ex = static_cast<u32>(__shfl_up(static_cast<int>(inc), 1, 64));
-  if (lane == 0) ex = 0;
-  __syncthreads();
-  if (lane == 63) lds[wave] = inc;
-  __syncthreads();
-  u32 base = 0, tot = 0;
-#pragma unroll
-  for (u32 w = 0; w < NW; ++w) {
-    const u32 s = lds[w];
-    if (w < wave) base = max(base, s);
-    tot = max(tot, s);
-  }
-  *total = tot;
-  return max(base, ex);
-}
-
 struct FastVisits {
   const u32* skey;    // slot of the visit at sorted position i
-  const u32* sray;    // its ray
-  const u32* sstep;   // its step on that ray
+  const u32* sinfo;   // its ray << kFastStepBits | its step on that ray
   const u64* shash;   // its hash
   const u32* voff;    // first visit of ray r (ray-major numbering)
   const u32* pos_of;  // sorted position of visit v
 };
-// is the visit at sorted position i performed under the current guess?  (steps 0 .. reach, the last one being the
-// operation that made the ray stop; a ray that never stops has reach == its whole walk)
-__device__ __forceinline__ bool fast_active(const FastVisits& V, const u32* __restrict__ reach, u32 i) { return V.sstep[i] <= reach[V.sray[i]]; }
-// sweep, part 1: eloc[i] = 1 + the last performed position before i inside i's tile (0 = none), tmax[tile] = same over the tile
-// prev_changed (both sweep kernels): the "changed" flag of the sweep before this one.  Zero means the iteration has converged:
-// both reach buffers hold the fixed point and eloc / tmax belong to it, so a sweep enqueued speculatively (the host reads the
-// flags one batch behind) returns at once instead of reproducing the fixed point.
-__global__ void __launch_bounds__(256) k_fast_scan_tiles(FastVisits V, const u32* __restrict__ reach, u32* __restrict__ eloc, u32* __restrict__ tmax,
-                                                         const Counters* cnt, u32 vcap, const u32* __restrict__ prev_changed) {
-  __shared__ u32 lds[4];
-  if (prev_changed && *prev_changed == 0u) return;
-  const u32 n = fast_num_visits(cnt, vcap);
-  const u32 n_tiles = (n + kFastTile - 1) / kFastTile;
-  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const u32 base = tile * kFastTile + threadIdx.x * 8;
-    u32 a[8], mx = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const u32 i = base + q;
-      a[q] = (i < n && fast_active(V, reach, i)) ? i + 1 : 0u;
-      mx = max(mx, a[q]);
-    }
-    u32 total;
-    u32 ex = block_exclusive_max<4>(mx, &total, lds);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (base + q < n) eloc[base + q] = ex;
-      ex = max(ex, a[q]);
-    }
-    if (threadIdx.x == 0) tmax[tile] = total;
-  }
+constexpr u32 kFastStepBits = 11, kFastStepMask = (1u << kFastStepBits) - 1u;  // walks of up to 2047 steps, 2^21 rays (else: the sequential kernel)
+// reach[] is updated in place by the relaxation: reads go past the non-coherent caches
+__device__ __forceinline__ u32 fast_ld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// is the visit at sorted position j performed under the current guess?  (steps 0 .. reach, the last one being the
+// operation that made the ray stop; a ray that never stops has reach == its whole list)
+__device__ __forceinline__ bool fast_active(const FastVisits& V, const u32* reach, u32 j) {
+  const u32 inf = V.sinfo[j];
+  return (inf & kFastStepMask) <= fast_ld(&reach[inf >> kFastStepBits]);
 }
-// 1 + sorted position of the last performed visit of slot `key` before position i (0 = none this frame).
-// eloc covers i's own tile; a slot's visits are contiguous, so earlier tiles only matter while the run reaches back
-// into them, and there the candidate is that tile's last performed visit (tmax): either it belongs to the run, or --
-// keys being sorted -- no performed visit of the run lies in that tile and the run starts behind it.
-__device__ __forceinline__ u32 fast_prev_performed(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tmax, u32 i, u32 key) {
-  const u32 e = eloc[i];
-  if (e > 0) return V.skey[e - 1] == key ? e : 0u;
-  u32 t = i / kFastTile;
-  while (t > 0 && V.skey[t * kFastTile - 1] == key) {
-    --t;
-    const u32 m = tmax[t];
-    if (m > 0) return V.skey[m - 1] == key ? m : 0u;
+// 1 + sorted position of the last performed visit of slot `key` before position i (0 = none this frame).  A slot's visits are
+// contiguous and in (ray, step) order (the sort is stable), so this is a walk back through the run -- eight positions at a
+// time: their keys and (ray, step) words are one batch of independent loads, the rays' reaches a second one, so a walk that
+// ends within a window costs two dependent round trips however many of the eight it looks at (one position at a time it was
+// three round trips per position, and a wave waits for its longest walk: 65 us per pass of the relaxation instead of 10).
+__device__ __forceinline__ u32 fast_prev_performed(const FastVisits& V, const u32* reach, u32 i, u32 key) {
+  constexpr u32 W = 8;
+  for (u32 base = i; base > 0;) {
+    u32 k[W], inf[W], rc[W];
+#pragma unroll
+    for (u32 w = 0; w < W; ++w) {
+      const bool in = base > w;  // position base - 1 - w exists
+      const u32 j = in ? base - 1u - w : 0u;
+      k[w] = in ? V.skey[j] : ~key;
+      inf[w] = V.sinfo[j];
+    }
+#pragma unroll
+    for (u32 w = 0; w < W; ++w) rc[w] = (k[w] == key) ? fast_ld(&reach[inf[w] >> kFastStepBits]) : 0u;
+#pragma unroll
+    for (u32 w = 0; w < W; ++w) {
+      if (k[w] != key) return 0u;  // the run starts here: no performed visit before i
+      if ((inf[w] & kFastStepMask) <= rc[w]) return base - w;
+    }
+    base = base > W ? base - W : 0u;
   }
   return 0u;
 }
 // was the slot of the visit at sorted position i last written with the same hash?
-__device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* __restrict__ eloc, const u32* __restrict__ tmax,
-                                               const u64* __restrict__ table_obs, u32 i) {
+__device__ __forceinline__ bool fast_collision(const FastVisits& V, const u32* reach, const u64* __restrict__ table_obs, u32 i) {
   const u32 key = V.skey[i];
-  const u32 e = fast_prev_performed(V, eloc, tmax, i, key);
+  const u64 mine = V.shash[i];
+  const u32 e = fast_prev_performed(V, reach, i, key);
   const u64 prev = e ? V.shash[e - 1] : table_obs[key];
-  return prev == V.shash[i];
+  return prev == mine;
 }
-// sweep, part 3: wave = ray.  Up to 256 steps of the walk are tested at once; the reference's "more than max_collisions
-// collisions in a row" is the first lane whose run of set bits (continued from the previous 64 steps) is long enough.
-__global__ void __launch_bounds__(256) k_fast_sweep(FastVisits V, int max_collisions, const u32* __restrict__ nfull, const u32* __restrict__ eloc,
-                                                    const u32* __restrict__ tmax, const u64* __restrict__ table_obs, const u32* __restrict__ reach_in,
-                                                    u32* __restrict__ reach_out, u32* __restrict__ changed, const Counters* cnt, u32 vcap,
-                                                    const u32* __restrict__ prev_changed) {
-  if (cnt->n_records > vcap) return;  // frame dropped (k_fast_visits): there are no visits to walk
-  if (prev_changed && *prev_changed == 0u) return;  // converged (see k_fast_scan_tiles); changed[this sweep] stays 0
-  const u32 n_rays = cnt->n_rays;
+
+// The visits in slot-sorted order: where each visit went (pos_of), and per sorted position its (ray, step) and its hash (so the
+// relaxation reads coalesced arrays instead of chasing visit -> ray -> offset).  Entries of unused list slots (key >= kFastSlots,
+// sorted last) are skipped.
+__global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ skey_sorted, const u32* __restrict__ vval_sorted, const u32* __restrict__ vray,
+                                                      const u64* __restrict__ vhash, const u32* __restrict__ voff, u32* __restrict__ pos_of, u32* __restrict__ sinfo,
+                                                      u64* __restrict__ shash, const u32* __restrict__ d_n, u32 vcap) {
+  const u32 n = min(*d_n, vcap);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (skey_sorted[i] >= kFastSlots) continue;
+    const u32 v = vval_sorted[i];
+    const u32 r = vray[v];
+    pos_of[v] = i;
+    sinfo[i] = (r << kFastStepBits) | (v - voff[r]);
+    shash[i] = vhash[v];
+  }
+}
+
+// ---- the relaxation: ONE persistent launch per round ------------------------------------------------------------------------
+// reach[r] <- where ray r stops given everybody's current reach, IN PLACE, pass after pass until a pass moves nothing.  The
+// system is triangular (a ray only depends on lower-numbered rays and on itself), so any schedule of re-evaluations converges to
+// the one fixed point, which is the sequential result; a pass that moved nothing has seen every ray at it.
+// A pass is a few microseconds of dependent gathers over ~10^5 visits, and a frame needs 5 (14-18 while the sphere is in view):
+// as launches with a host look at the "changed" flag in between (round 2) that was 0.11 ms per frame plus the round trips.  Here
+// a small grid (kFastRelaxGroups workgroups, far fewer than the chip holds at once) stays resident and meets at a barrier
+// after every pass.  The barrier cannot hang: a workgroup that waits longer than kFastBarrierPolls polls gives up, raises `abort`,
+// everybody leaves, and the frame is redone by k_fast_sequential -- exact either way, and no host round trip.
+//   short lists (<= lpr steps: every list of round 0, the lists of the rays that did not grow in round 1): lpr lanes per ray,
+//     64 / lpr rays per wave; the collision flags of a ray are one ballot, its stop a few bit operations
+//   long lists (round 1: the rays that got their whole walk): one wave per ray, up to 256 steps tested at once
+constexpr u32 kFastRelaxGroups = 128, kFastRelaxThreads = 512;
+constexpr u32 kFastBarrierPolls = 2000000;  // x ~0.5 us: about a second
+constexpr u32 kFastMaxPasses = 4096;
+typedef FastCtl::Bar FastBarrier;  // arrived: workgroups that have arrived, over all passes (never reset: pass p is complete at groups * (p + 1));
+                                   // epoch: passes completed; moved / want [pass % 3]: flags of that pass; abort: a workgroup gave up waiting
+// The barrier is the "one monotonic counter" form: every wave drains its stores, the workgroup meets, ONE lane releases
+// (agent scope), adds to the counter and polls it with relaxed loads and s_sleep -- a word that is only ever written by
+// atomic adds, which is what makes a relaxed poll see it across the XCDs' private L2s: polling a separate "epoch" word
+// published by a store was seen 15 ms late, and an acquire in the polling loop invalidates caches on every poll (110 us per
+// pass) -- then acquires ONCE, and the workgroup meets again.
+__device__ __forceinline__ bool fast_grid_barrier(FastBarrier* b, u32 pass, u32* lds_ok, int fences) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 target = gridDim.x * (pass + 1u);
+    bool ok = true;
+    if (fences) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    (void)atomicAdd(&b->arrived, 1u);
+    u32 polls = 0;
+    while (__hip_atomic_load(&b->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++polls > kFastBarrierPolls || (polls % 64u == 0u && __hip_atomic_load(&b->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        (void)atomicOr(&b->abort, 1u);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (fences) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (__hip_atomic_load(&b->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = false;
+    *lds_ok = ok ? 1u : 0u;
+  }
+  __syncthreads();
+  return *lds_ok != 0u;
+}
+// first step at which more than max_collisions collisions in a row have happened, from the collision flags of a list of ns <= 32 steps
+__device__ __forceinline__ u32 fast_stop_from_bits(u32 m, u32 ns, int max_collisions) {
+  u32 x = m;
+  for (int k = 1; k <= max_collisions && x; ++k) x &= m >> k;  // bit s: collisions at s, s + 1, ..., s + max_collisions
+  return x ? static_cast<u32>(__ffs(static_cast<int>(x))) - 1u + static_cast<u32>(max_collisions) : ns;
+}
+__global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, int max_collisions, const u32* __restrict__ list_len, const u32* __restrict__ nfull,
+                                                                  const u64* __restrict__ table_obs, u32* reach, FastCtl* ctl, int round, u32 lpr,
+                                                                  const u32* __restrict__ long_list, const u32* __restrict__ d_n_rays, int fences) {
+  __shared__ u32 lds_ok;
+  FastBarrier* bar = &ctl->bar[round];
+  if (ctl->overflow || (round == 1 && (ctl->grew == 0u || ctl->settled[0] == 0u))) return;  // (uniform over the grid: nobody waits for anybody)
+  const u32 n_rays = *d_n_rays;
+  const u32 n_long = round == 1 ? ctl->n_long : 0u;
   const u32 lane = lane_id();
   const u32 n_waves = (gridDim.x * blockDim.x) >> 6;
-  bool any = false;
-  for (u32 r = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < n_rays; r += n_waves) {
-    const u32 ns = nfull[r], off = V.voff[r];
-    u32 carry = 0, stop = ns;
-    // Most rays stop within their first few steps and every tested step costs half a dozen gathers, so the walk is
-    // tested in growing segments: 16 steps, the rest of the first 64, then 256 at a time (four independent gathers
-    // per lane in flight) for the few rays that are still going.
-    u32 base = 0, seg = 16;
-    while (base < ns && stop == ns) {
-      const u32 len = uniform_u32(min(seg, ns - base));
-      bool coll[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32 q = 64u * j + lane;
-        coll[j] = (q < len) && fast_collision(V, eloc, tmax, table_obs, V.pos_of[off + base + q]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (stop != ns || 64u * j >= len) break;
-        const u32 sub = uniform_u32(min(64u, len - 64u * j));  // lanes of this group that hold a step
-        const u64 m = __ballot(coll[j]);
-        // length of the run of collisions that ends at this lane
-        const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-        const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
-        const u64 hit = __ballot(coll[j] && run > static_cast<u32>(max_collisions));
-        if (hit) stop = base + 64u * j + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
-        carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), static_cast<int>(sub - 1u)));
-      }
-      base += len;
-      seg = (base < 64u) ? 64u - base : 256u;
+  const u32 wave0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const u32 per_wave = 64u / lpr;     // rays of a wave in the short-list part (lpr = 8, 16 or 32)
+  const u32 sub = lane / lpr, s = lane % lpr;
+  const u64 sub_mask = (lpr == 32u ? 0xFFFFFFFFull : ((1ull << lpr) - 1ull));
+  for (u32 pass = 0; pass < kFastMaxPasses; ++pass) {
+    const u32 f = pass % 3u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the flags of the pass after this one: last read behind the barrier before the previous one
+      (void)atomicAnd(&bar->moved[(pass + 1u) % 3u], 0u);  // (every access to these words is an atomic: they are seen across the XCDs' L2s)
+      (void)atomicAnd(&bar->want[(pass + 1u) % 3u], 0u);
     }
-    if (lane == 0) {
-      reach_out[r] = stop;
-      any |= (stop != reach_in[r]);
+    bool any = false, wants = false;
+    // short lists
+    for (u32 g = wave0; g * per_wave < n_rays; g += n_waves) {
+      const u32 r = g * per_wave + sub;
+      u32 ns = 0, off = 0;
+      if (r < n_rays) {
+        ns = list_len[r];
+        off = V.voff[r];
+        if (ns > lpr) ns = 0xFFFFFFFFu;  // a long list: the wave-per-ray part below
+      }
+      // The steps up to the ray's present stop first: a stable ray (most of them, from the second pass on) is confirmed by those
+      // alone, and they are the cheap ones -- near the surface every slot's run is full of performed visits, while the voxels in
+      // front of it, steps 4 .. 7 of every ray around, have runs of nothing but unperformed visits that a look-up has to walk
+      // through (a wave waits for its longest walk).  Only a ray that does NOT stop within them looks at the rest of its list.
+      const bool short_ray = r < n_rays && ns != 0xFFFFFFFFu;
+      const u32 old = short_ray ? fast_ld(&reach[r]) : 0u;
+      const u32 first = min(ns, old + 1u);  // steps [0, first)
+      const u32 pos = (short_ray && s < ns) ? V.pos_of[off + s] : 0u;
+      bool coll = short_ray && s < first && fast_collision(V, reach, table_obs, pos);
+      u32 m = static_cast<u32>((__ballot(coll) >> (sub * lpr)) & sub_mask);
+      u32 stop = fast_stop_from_bits(m, ns, max_collisions);
+      const bool more = short_ray && stop >= first && first < ns;  // (uniform over the ray's lanes)
+      if (__ballot(more)) {
+        if (more && s >= first && s < ns) coll = fast_collision(V, reach, table_obs, pos);
+        m = static_cast<u32>((__ballot(coll) >> (sub * lpr)) & sub_mask);
+        if (more) stop = fast_stop_from_bits(m, ns, max_collisions);
+      }
+      if (short_ray && s == 0) {
+        if (stop == ns && ns < nfull[r]) wants = true;
+        if (stop != old) {
+          __hip_atomic_store(&reach[r], stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          any = true;
+        }
+      }
+    }
+    // long lists: up to 256 steps of a walk are tested at once; the reference's "more than max_collisions collisions in a row" is
+    // the first lane whose run of set bits (continued from the previous 64 steps) is long enough
+    for (u32 q = wave0; q < n_long; q += n_waves) {
+      const u32 r = uniform_u32(long_list[q]);
+      const u32 ns = uniform_u32(list_len[r]), off = uniform_u32(V.voff[r]);
+      u32 carry = 0, stop = ns;
+      // most rays stop within their first few steps and every tested step costs half a dozen gathers, so the walk is tested in
+      // growing segments: 16 steps, the rest of the first 64, then 256 at a time (four independent gathers per lane in flight)
+      u32 base = 0, seg = 16;
+      while (base < ns && stop == ns) {
+        const u32 len = uniform_u32(min(seg, ns - base));
+        bool coll[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 t = 64u * j + lane;
+          coll[j] = (t < len) && fast_collision(V, reach, table_obs, V.pos_of[off + base + t]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (stop != ns || 64u * j >= len) break;
+          const u32 cnt_in = uniform_u32(min(64u, len - 64u * j));  // lanes of this group that hold a step
+          const u64 m = __ballot(coll[j]);
+          // length of the run of collisions that ends at this lane
+          const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+          const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
+          const u64 hit = __ballot(coll[j] && run > static_cast<u32>(max_collisions));
+          if (hit) stop = base + 64u * j + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
+          carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), static_cast<int>(cnt_in - 1u)));
+        }
+        base += len;
+        seg = (base < 64u) ? 64u - base : 256u;
+      }
+      if (lane == 0) {
+        if (stop == ns && ns < nfull[r]) wants = true;
+        if (stop != fast_ld(&reach[r])) {
+          __hip_atomic_store(&reach[r], stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          any = true;
+        }
+      }
+    }
+    // one word per flag for the whole grid: only the first few waves that have something to say write it
+    if (__ballot(any) && lane == 0 && __hip_atomic_load(&bar->moved[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) (void)atomicOr(&bar->moved[f], 1u);
+    if (__ballot(wants) && lane == 0 && __hip_atomic_load(&bar->want[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) (void)atomicOr(&bar->want[f], 1u);
+    if (!fast_grid_barrier(bar, pass, &lds_ok, fences)) return;  // gave up: settled[round] stays 0
+    if (__hip_atomic_load(&bar->moved[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {  // a pass that moved nothing: every ray is at the fixed point
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->want_more[round] = __hip_atomic_load(&bar->want[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl->passes[round] = pass + 1u;
+        ctl->settled[round] = 1u;
+      }
+      return;
     }
   }
-  // one word for the whole grid: only the first few waves that changed something write it (a same-address atomic per wave of the
-  // first sweep, where every ray changes, was 50 us of serialised traffic)
-  if (any && __hip_atomic_load(changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(changed, 1u);
 }
-// after the last sweep: the table keeps the hash of the last performed operation on each slot
-__global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V, const u32* __restrict__ reach, const u32* __restrict__ eloc, const u32* __restrict__ tmax,
-                                                         u64* __restrict__ table_obs, const Counters* cnt, u32 vcap) {
-  const u32 n = fast_num_visits(cnt, vcap);
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u32 key = V.skey[i];
-    if (i + 1 < n && V.skey[i + 1] == key) continue;  // not the end of the slot's run
-    const u32 e = fast_active(V, reach, i) ? i + 1 : fast_prev_performed(V, eloc, tmax, i, key);
-    if (e) table_obs[key] = V.shash[e - 1];
-  }
-}
-// Candidate visits are generated for the first cap[r] steps of a ray only (most rays stop within a few steps, their walks
-// are hundreds of voxels long at fine voxel sizes).  A converged ray that reached its cap without stopping may want to go
-// on: it gets its whole walk and the round is repeated with the longer list; rays that stopped are final as far as their own
-// list goes, and the fixed point of the last round (nobody at a cap short of its whole walk) contains every performed visit,
-// so it is the sequential result.
-__global__ void __launch_bounds__(256) k_fast_grow_caps(const u32* __restrict__ nfull, u32* __restrict__ cap, u32* __restrict__ reach_a, u32* __restrict__ reach_b,
-                                                        u32* __restrict__ grew, const Counters* cnt) {
-  const u32 n_rays = cnt->n_rays;
+
+// Candidate visits are generated for the first cap0 steps of a ray only (most rays stop within a few steps, their walks are
+// hundreds of voxels long).  A converged ray that reached the end of its list without stopping wants to go on: it gets its whole
+// walk and round 1 relaxes again over the longer lists, from the fixed point of round 0.  The fixed point of a round in which
+// nobody is at the end of a list shorter than its walk contains every performed visit, so it is the sequential result.
+// The longer lists change what the rays behind them see: a ray that stopped at its sixth voxel in round 0 may stop at its third
+// now, its later visits are no longer performed, and a ray that collided with those goes on instead -- past the end of its
+// capped list, once in a few frames.  So every other ray's list grows as well in round 1, to cap1 steps (a few times the cap of
+// round 0): room for such second-order moves.  A ray that still ends up at the end of a list shorter than its walk sends the
+// frame to k_fast_sequential.
+__global__ void __launch_bounds__(256) k_fast_grow(const u32* __restrict__ nfull, u32* __restrict__ cap, u32* reach, FastCtl* ctl, u32 cap1,
+                                                   u32* __restrict__ long_list, const u32* __restrict__ d_n_rays) {
+  const u32 n_rays = *d_n_rays;
+  if (ctl->overflow || ctl->settled[0] == 0u || ctl->want_more[0] == 0u) return;  // round 0 did not settle (k_fast_sequential takes over) / nobody wants more
   bool any = false;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
     const u32 c = cap[r], nf = nfull[r];
-    if (c < nf && reach_a[r] >= c) {
-      const u32 nc = nf;  // a ray that got through its first steps unstopped mostly goes all the way: take the whole walk
-      cap[r] = nc;
-      reach_a[r] = nc;  // guess: it keeps going
-      reach_b[r] = nc;
+    if (c < nf && reach[r] >= c) {
+      cap[r] = nf;    // a ray that got through its first steps unstopped mostly goes all the way: take the whole walk
+      reach[r] = nf;  // guess: it keeps going
+      if (nf > cap1) long_list[atomicAdd(&ctl->n_long, 1u)] = r;  // (one wave each in round 1; their order does not matter)
       any = true;
+    } else if (c < nf) {
+      cap[r] = min(nf, cap1);  // (its reach stays: the guess of round 0's fixed point)
     }
   }
-  if (__ballot(any) && lane_id() == 0 && __hip_atomic_load(grew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(grew, 1u);
+  if (__ballot(any) && lane_id() == 0) {
+    if (__hip_atomic_load(&ctl->grew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&ctl->grew, 1u);
+    ctl->scan_n = n_rays;  // (every writer stores the same value)
+  }
+}
+// round 1: offsets of the grown lists (exclusive scan of cap over the rays, one workgroup; nothing to do without growth)
+__global__ void __launch_bounds__(1024) k_fast_scan_caps(const u32* __restrict__ cap, u32* __restrict__ voff, FastCtl* ctl, u32 n_max, u32 vcap) {
+  __shared__ u32 lds[16];
+  const u32 n = min(ctl->scan_n, n_max);
+  if (n == 0) return;
+  u32 carry = 0;
+  for (u32 base = 0; base < n; base += 1024 * 4) {
+    const u32 i0 = base + threadIdx.x * 4;
+    u32 v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = (i0 + q < n) ? cap[i0 + q] : 0u;
+      sum += v[q];
+    }
+    u32 total;
+    u32 ex = carry + block_exclusive_scan<16>(sum, &total, lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i0 + q < n) voff[i0 + q] = ex;
+      ex += v[q];
+    }
+    carry += total;  // (sums beyond 2^32 cannot occur: the lists' total is bounded by the record capacity, < 2^31)
+  }
+  if (threadIdx.x == 0) {
+    ctl->n_visits[1] = carry > vcap ? 0u : carry;
+    if (carry > vcap) ctl->overflow = 1u;
+  }
+}
+// the same bookkeeping behind the three-launch scan (many rays: fine voxels)
+__global__ void k_fast_scan_caps_done(FastCtl* ctl, u32 vcap) {
+  if (ctl->scan_n == 0u) ctl->n_visits[1] = 0u;
+  if (ctl->n_visits[1] > vcap) {
+    ctl->n_visits[1] = 0u;
+    ctl->overflow = 1u;
+  }
+}
+
+// did the relaxation produce the frame's result?  (round 0 settled; if it grew lists, round 1 settled too, its lists fit, and
+// nobody is at the end of a list shorter than its walk)
+__device__ __forceinline__ bool fast_solved(const FastCtl* ctl) {
+  if (ctl->overflow || ctl->settled[0] == 0u) return false;
+  if (ctl->grew == 0u) return ctl->want_more[0] == 0u;
+  return ctl->settled[1] != 0u && ctl->want_more[1] == 0u;
+}
+// The relaxation did not produce the result (a ray outgrew its round-1 list -- once in a few hundred frames of the benchmark
+// stream with cap1 = cap0, never seen with cap1 = 4 cap0 --, lists that do not fit, a barrier that gave up): ONE lane runs the
+// reference's loop as it is written -- rays in visiting order, replaceHash on the table itself.  Slow (tens of milliseconds),
+// exact, and with no host round trip either.
+__global__ void __launch_bounds__(64) k_fast_sequential(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ table_obs, u32* reach,
+                                                        FastCtl* ctl, int force, const u32* __restrict__ d_n_rays) {
+  if (fast_solved(ctl) && !force) return;  // (force: COX_FAST_SEQUENTIAL=1, so that the tests can take this path on any frame)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const FrameParams P = *Pp;
+  const u32 n_rays = *d_n_rays;
+  for (u32 r = 0; r < n_rays; ++r) {
+    const u32 ns = R.nsteps[r];
+    Dda d;
+    dda_setup(d, P, F3{R.px[r], R.py[r], R.pz[r]}, (R.flags[r] & 2u) != 0);
+    int collisions = 0;
+    u32 s = 0;
+    for (; s < ns; ++s) {
+      const u64 h = long_index_hash(d.c[0], d.c[1], d.c[2]) + FF.off_obs;
+      dda_step(d);
+      const u32 slot = static_cast<u32>(h) & kFastSlotMask;
+      if (table_obs[slot] == h) {
+        ++collisions;
+      } else {
+        table_obs[slot] = h;
+        collisions = 0;
+      }
+      if (collisions > FF.max_collisions) break;
+    }
+    reach[r] = s;
+  }
+  ctl->sequential = 1u;
+}
+// after the relaxation: the table keeps the hash of the last performed operation on each slot
+__global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V0, FastVisits V1, const u32* reach, u64* __restrict__ table_obs, const FastCtl* ctl,
+                                                         u32 vcap0, u32 vcap1, u32* __restrict__ stats) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // run totals (cox_integrator_fast_stats): how often the relaxation was not enough, and how much of it there was
+    if (ctl->sequential) atomicAdd(&stats[0], 1u);
+    if (ctl->sequential && ctl->settled[0] && ctl->grew && ctl->settled[1] && ctl->want_more[1]) atomicAdd(&stats[4], 1u);  // ... because a ray outgrew its round-1 list
+    if (ctl->sequential && (ctl->bar[0].abort || ctl->bar[1].abort)) atomicAdd(&stats[5], 1u);                               // ... because a barrier gave up
+    if (ctl->grew) atomicAdd(&stats[1], 1u);
+    atomicAdd(&stats[2], ctl->passes[0]);
+    atomicAdd(&stats[3], ctl->passes[1]);
+  }
+  if (ctl->sequential) return;  // the sequential kernel wrote the table as it went
+  const bool r1 = ctl->grew != 0u;
+  const FastVisits& V = r1 ? V1 : V0;
+  const u32 n = r1 ? min(ctl->n_visits[1], vcap1) : min(ctl->n_visits[0], vcap0);
+  // thread = performed visit: it is its slot's last one unless a later visit of the run is performed too (walking FORWARD from the
+  // performed visits: the runs of nothing but unperformed visits -- the voxels in front of the surfaces -- cost nothing)
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 key = V.skey[i];
+    if (key >= kFastSlots || !fast_active(V, reach, i)) continue;
+    bool last = true;
+    constexpr u32 W = 8;
+    for (u32 base = i + 1; last && base < n; base += W) {
+      u32 k[W], inf[W], rc[W];
+#pragma unroll
+      for (u32 w = 0; w < W; ++w) {
+        const bool in = base + w < n;
+        const u32 j = in ? base + w : i;
+        k[w] = in ? V.skey[j] : ~key;
+        inf[w] = V.sinfo[j];
+      }
+#pragma unroll
+      for (u32 w = 0; w < W; ++w) rc[w] = (k[w] == key) ? fast_ld(&reach[inf[w] >> kFastStepBits]) : 0u;
+      bool end = false;
+#pragma unroll
+      for (u32 w = 0; w < W; ++w) {
+        if (end || !last) continue;
+        if (k[w] != key) end = true;                                 // the run ends here
+        else if ((inf[w] & kFastStepMask) <= rc[w]) last = false;  // a later performed visit
+      }
+      if (end) break;
+    }
+    if (last) table_obs[key] = V.shash[i];
+  }
 }
 // hand the rays over to the record pipeline: a ray emits its first reach[r] voxels
 __global__ void __launch_bounds__(256) k_fast_finish(RayArrays R, const u32* __restrict__ reach, Counters* cnt) {

@@ -42,6 +42,22 @@ using namespace cox;
 // =================================================================================================
 // device side
 // =================================================================================================
+// per-frame control words of the observed-set solve of the fast integrator (cox_fast.hpp; part of Counters, zeroed with it at frame start)
+struct FastCtl {
+  u32 n_visits[2];   // candidate visits of round 0 (cap0 per ray) / round 1 (sum of the grown lists; 0 = no round 1)
+  u32 settled[2];    // [round]: the relaxation reached a pass that moved nothing
+  u32 want_more[2];  // [round]: at that fixed point some ray is at the end of a list shorter than its walk, unstopped
+  u32 passes[2];     // [round]: passes the relaxation took
+  u32 grew;          // round 1 runs (k_fast_grow gave some ray its whole walk)
+  u32 n_long;        // round 1: rays with a list longer than cap1 (one wave each)
+  u32 scan_n;        // rays the cap scan of round 1 covers (0 = no round 1)
+  u32 overflow;      // lists that do not fit their buffers
+  u32 sequential;    // the sequential kernel produced this frame's result (k_fast_sequential)
+  u32 pad[3];
+  struct Bar {
+    u32 arrived, pad0[15], epoch, pad1[15], moved[3], want[3], abort, pad2[9];
+  } bar[2];
+};
 struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_valid;      // points that passed isPointValid
   u32 n_rays;       // rays cast (simple: valid points, merged: bundles)
@@ -57,6 +73,7 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_sorted_valid;  // valid points as seen in the sorted bundling keys (merged)
   u32 n_piece_slots;   // piece path: sum of the rays' piece bounds = slots of the piece arrays in use
   u32 n_expanded;      // piece partition: records written by k_piece_expand (what k_apply_block reads)
+  FastCtl fast;
   // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
   // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
   // [s][0] valid points, [s][1] updates, [s][2] voxels, [s][3] long runs, [s][4] rays
@@ -169,8 +186,18 @@ __global__ void __launch_bounds__(256) k_rays_simple(const FrameParams* __restri
 // smallest sequence number of the group as a candidate for the bundle's first visit.
 // First kernel of a frame: with by_value the frame's parameter block arrives as a kernel argument and workgroup 0
 // stores it for the kernels that follow (saves the 4 us H2D blit per frame); captured stage graphs keep the copy.
-__global__ void __launch_bounds__(256) k_bundle_insert(FrameParams* __restrict__ Pp, FrameParams Pv, int by_value, u64* __restrict__ fh_keys,
+// n_dev (by_value only): the frame's point count is still on the device (depth front end): every workgroup takes it from there.
+__device__ __forceinline__ u32 pow2_above(u32 n) {  // power of two > n (FrameParams::np2)
+  u32 p = 1;
+  while (p <= n && p < 0x80000000u) p <<= 1;
+  return p;
+}
+__global__ void __launch_bounds__(256) k_bundle_insert(FrameParams* __restrict__ Pp, FrameParams Pv, int by_value, const u32* __restrict__ n_dev, u64* __restrict__ fh_keys,
                                                        u32* __restrict__ fh_first, u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
+  if (by_value && n_dev) {
+    Pv.n_points = min(*n_dev, Pv.n_points);
+    Pv.np2 = pow2_above(Pv.n_points);
+  }
   if (by_value && blockIdx.x == 0 && threadIdx.x == 0) *Pp = Pv;
   const FrameParams P = by_value ? Pv : *Pp;
   const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +255,12 @@ __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams* __restrict__
   if (idx < P.n_points) pslot[idx] = slot;  // kInvalid for points that are not integrated; indexed by point (coalesced)
   const u64 m = __ballot(valid && slot != kInvalid);
   if (lane == 0 && m) atomicAdd(&cnt->shard[(idx >> 6) & 63u][kShValid], static_cast<u32>(__popcll(m)));
+}
+// the same for the frames whose parameter block is uploaded by a copy (simple, fast, captured stage graphs): one thread patches it
+__global__ void k_params_count(FrameParams* __restrict__ Pp, const u32* __restrict__ n_dev) {
+  const u32 n = min(*n_dev, Pp->n_points);
+  Pp->n_points = n;
+  Pp->np2 = pow2_above(n);
 }
 // sort key of a point = (clearing ? np2 : 0) + first sequence number of its bundle; value = seq.  Also publishes the
 // key width of the bundling sort.
@@ -1008,28 +1041,64 @@ __global__ void __launch_bounds__(256) k_emit_wave(const FrameParams* __restrict
 #include "cox_apply_tile.hpp"
 
 // ---- depth front end ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_depth_flags(const float* __restrict__ depth, u32 n, u32* __restrict__ flag) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float d = depth[i];
-  flag[i] = (isfinite(d) && d > 0.0f) ? 1u : 0u;
+// depth image -> point list in row-major pixel order (the order depth_image_proc produces), in two launches:
+//   k_depth_count   valid pixels per tile of 2048
+//   k_depth_points  every workgroup adds up the counts of the tiles before its own (a 640 x 480 image has 150), scans its tile and
+//                   writes its points; the last tile leaves the frame's point count on the device -- it never visits the host
+constexpr u32 kDepthTile = 2048;
+__device__ __forceinline__ bool depth_valid(float d) { return isfinite(d) && d > 0.0f; }
+__global__ void __launch_bounds__(256) k_depth_count(const float* __restrict__ depth, u32 n, u32* __restrict__ tile_sums) {
+  __shared__ u32 lds[4];
+  const u32 n_tiles = (n + kDepthTile - 1) / kDepthTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    u32 c = 0;
+#pragma unroll
+    for (u32 q = 0; q < kDepthTile / 256; ++q) {
+      const u32 i = tile * kDepthTile + q * 256 + threadIdx.x;
+      c += (i < n && depth_valid(depth[i])) ? 1u : 0u;
+    }
+    u32 tot;
+    (void)block_exclusive_scan<4>(c, &tot, lds);
+    if (threadIdx.x == 0) tile_sums[tile] = tot;
+  }
 }
 __global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ depth, const uint8_t* __restrict__ rgba, int w, int h, float fx, float fy,
-                                                      float cx, float cy, const u32* __restrict__ pos, float* __restrict__ xyz,
-                                                      uint8_t* __restrict__ rgba_out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                      float cx, float cy, const u32* __restrict__ tile_sums, float* __restrict__ xyz,
+                                                      uint8_t* __restrict__ rgba_out, u32* __restrict__ n_out) {
+  __shared__ u32 lds[4], lds2[4];
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
-  if (i >= n) return;
-  const float d = depth[i];
-  if (!(isfinite(d) && d > 0.0f)) return;
-  const u32 o = pos[i];
-  const u32 u = i % static_cast<u32>(w), v = i / static_cast<u32>(w);
-  const float xn = (static_cast<float>(u) - cx) / fx;
-  const float yn = (static_cast<float>(v) - cy) / fy;
-  xyz[3 * o] = d * xn;
-  xyz[3 * o + 1] = d * yn;
-  xyz[3 * o + 2] = d;
-  if (rgba_out) reinterpret_cast<u32*>(rgba_out)[o] = rgba ? reinterpret_cast<const u32*>(rgba)[i] : 0u;
+  const u32 n_tiles = (n + kDepthTile - 1) / kDepthTile;
+  for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    u32 below = 0;
+    for (u32 t = threadIdx.x; t < tile; t += 256) below += tile_sums[t];
+    u32 base;
+    (void)block_exclusive_scan<4>(below, &base, lds2);
+    // thread t owns the 8 consecutive pixels [tile * 2048 + 8 t, + 8)
+    const u32 i0 = tile * kDepthTile + threadIdx.x * 8;
+    float d[8];
+    u32 c = 0;
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      d[q] = (i0 + q < n) ? depth[i0 + q] : 0.0f;
+      c += depth_valid(d[q]) ? 1u : 0u;
+    }
+    u32 tot;
+    u32 o = base + block_exclusive_scan<4>(c, &tot, lds);
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      if (!depth_valid(d[q])) continue;
+      const u32 i = i0 + q;
+      const u32 u = i % static_cast<u32>(w), v = i / static_cast<u32>(w);
+      const float xn = (static_cast<float>(u) - cx) / fx;
+      const float yn = (static_cast<float>(v) - cy) / fy;
+      xyz[3 * o] = d[q] * xn;
+      xyz[3 * o + 1] = d[q] * yn;
+      xyz[3 * o + 2] = d[q];
+      if (rgba_out) reinterpret_cast<u32*>(rgba_out)[o] = rgba ? reinterpret_cast<const u32*>(rgba)[i] : 0u;
+      ++o;
+    }
+    if (tile + 1 == n_tiles && threadIdx.x == 0) *n_out = base + tot;
+  }
 }
 
 // ---- self-test: the hoisted-reciprocal division of k_bundle_merge against the compiler's IEEE '/' -----------------
@@ -1120,20 +1189,32 @@ struct RecordSet {  // lives B1 .. B2
 };
 
 // buffers of the fast integrator (method == COX_METHOD_FAST only); see cox_fast.hpp
-constexpr int kFastMaxSweeps = 512;
+constexpr u32 kFastCap0Max = 32;  // candidate steps per ray in round 0: FastState::cap0 (COX_FAST_CAP=cap0,cap1)
+struct VisitSet {  // the candidate visits of one round: ray-major arrays + their slot-sorted view
+  u32 *key[2] = {nullptr, nullptr}, *val[2] = {nullptr, nullptr};  // sort ping-pong: slot, visit id
+  u64 *vhash = nullptr, *shash = nullptr;                         // hash of visit v / of the visit at sorted position i
+  u32 *vray = nullptr, *pos_of = nullptr, *sinfo = nullptr, *voff = nullptr;
+  u32 cap = 0;                 // visits the arrays hold
+  int sorted = 0;              // which ping-pong buffer holds the sorted keys
+  hipEvent_t done = nullptr;   // the solve of the frame that used the set is complete
+  bool used = false;
+};
 struct FastState {
-  u64 *fhash = nullptr, *vhash = nullptr, *table_start = nullptr, *table_obs = nullptr;
-  u64* shash = nullptr;
-  u32* cap = nullptr;   // candidate-visit cap per ray
-  u32 cap0 = 0xFFFFFFFFu;  // initial cap (no capping unless walks are long: set from the configuration)
-  u32 *fresh = nullptr, *rank = nullptr, *vray = nullptr, *pos_of = nullptr, *eloc = nullptr, *tmax = nullptr, *sray = nullptr, *sstep = nullptr;
-  u32* reach[2] = {nullptr, nullptr};
-  u32* d_changed = nullptr;  // [kFastMaxSweeps]
-  u32* h_changed = nullptr;  // pinned mirror
-  hipEvent_t ev[2] = {nullptr, nullptr};  // "this batch's flags have reached the host"
+  u64 *fhash = nullptr, *table_start = nullptr, *table_obs = nullptr;
+  u32 *fresh = nullptr, *rank = nullptr;
+  u32* cap[kFrameSets] = {};    // candidate-list length per ray (lives from the front to the end of the solve, like the frame set)
+  u32* reach[kFrameSets] = {};  // voxels each ray updates: relaxed in place
+  VisitSet vs0[2];              // round 0: written by the front of frame t (start-set stream), read by its solve -- two frames' worth
+  VisitSet vs1;                 // round 1: lives inside one solve
+  u32* long_list = nullptr;     // round 1: the rays with a list longer than cap1
+  int fences = 1;                 // COX_FAST_FENCE (experiments): release / acquire fences in the relaxation's barrier
+  u32 relax_groups = kFastRelaxGroups;  // COX_FAST_GROUPS (experiments): workgroups of the relaxation (all resident at once: far fewer than the chip holds)
+  bool force_sequential = false;  // COX_FAST_SEQUENTIAL=1 (tests): every frame is redone by k_fast_sequential
+  u32 cap0 = 8, cap1 = 16;      // candidate steps per ray in round 0; list length of the rays that did not get their whole walk in round 1
+  u32* d_stats = nullptr;       // [8] run totals: frames redone by the sequential kernel, frames with a round 1, passes of the relaxation (round 0, round 1), ...
   u64 off_start = 0, off_obs = 0;  // ApproxHashSet::offset_
   int reset_counter = 0;
-  uint64_t sweeps_total = 0, frames = 0;
+  uint64_t frames = 0;
 };
 
 // ---- submission thread ------------------------------------------------------------------------------------------------
@@ -1205,7 +1286,7 @@ void cox_drain_submitters() {
 }
 
 struct cox_integrator {
-  Submitter* submitter = nullptr;  // simple / merged; COX_SUBMIT_THREAD=0 turns it off
+  Submitter* submitter = nullptr;  // COX_SUBMIT_THREAD=0 turns it off
   uint64_t host_ns = 0, host_wait_ns = 0, host_frames = 0;  // time the caller's thread spends inside the integrate call (enqueueing, waiting for a free slot)
   cox_projective* proj = nullptr;  // method == COX_METHOD_PROJECTIVE: everything else below stays empty
   cox_layer* layer = nullptr;
@@ -1245,16 +1326,24 @@ struct cox_integrator {
   hipEvent_t ev_producer = nullptr, ev_inputs_read = nullptr;
   float* own_xyz[kStageSets] = {};  // staging for host / depth inputs: one per bundle set (read by stages H .. M of the frame)
   uint8_t* own_rgba[kStageSets] = {};
-  u32* h_depth_n = nullptr;  // pinned: point count of the depth image being converted
-  u32* depth_flag = nullptr;
-  u32* d_depth_n = nullptr;  // point count of the depth front end
-  SortWorkspace sort_pts, sort_rec, sort_vis;  // sort_vis: the fast integrator's visit sort (runs beside the previous frame's record sort)
+  u32* depth_flag = nullptr;  // depth front end: valid pixels per tile
+  u32* d_depth_n = nullptr;   // [kStageSets] point count of the depth image converted into each staging set: it stays on the device
+  // the engine's own input stream: H2D copies of host buffers (cox_integrate_points_async) run here, beside the kernels of earlier frames
+  hipStream_t st_in = nullptr;
+  hipEvent_t in_ready[kStageSets] = {};  // staging set k has been filled (the frame's first stage waits for it)
+  hipEvent_t in_free[kStageSets] = {};   // the frame that read staging set k last has read it for the last time
+  bool in_used[kStageSets] = {};
+  float* pin_xyz[kStageSets] = {};       // pinned bounce buffers for pageable host inputs (a pinned caller buffer is copied from directly)
+  uint8_t* pin_rgba[kStageSets] = {};
+  u32 pin_cap = 0;
+  SortWorkspace sort_pts, sort_rec, sort_vis, sort_vis1;  // sort_vis / sort_vis1: the fast integrator's visit sorts (round 0 on the start-set stream, round 1 on the solve's)
   ScanWorkspace scanws_a, scanws_b, scanws_d, scanws_f;
   u32 scan_cap = 0;
   Counters* h_ring = nullptr;  // pinned, kStatRing entries
   uint64_t frame_no = 0;       // frames enqueued
   cox_frame_stats last{};      // host-known part of the last frame's stats
   bool last_has_counts = false;
+  bool last_count_on_device = false;  // the last frame's point count was produced on the device (fold_counters fetches it)
   // stage graphs: [stage][frame set index] (the bundle / record set index is the frame set index & 1)
   bool use_graphs = true;
   hipGraphExec_t graphs[kNumStages][kFrameSets] = {};
@@ -1318,6 +1407,7 @@ static int sync_all(cox_integrator* I) {
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
   if (I->st_alt) COX_HIP(hipStreamSynchronize(I->st_alt));
+  if (I->st_in) COX_HIP(hipStreamSynchronize(I->st_in));
   return COX_OK;
 }
 
@@ -1373,10 +1463,6 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   // unless that bound exceeds the 2^31 record limit of the 32-bit offsets
   I->steps_max = max_steps_per_ray(I);
   I->small_axis_cap = (I->steps_max - 1) / 3 + 2 <= kAxisCapSmall;  // steps_max = 3 * (planes per axis bound) + 1
-  // fast: cap the candidate-visit lists only where walks are long (2 cm and finer with the reference's ray lengths); at 5 cm
-  // the second round costs more than the shorter lists save
-  // (measured, frames/s at 2 cm / 1 cm: cap 8: 599 / 121, 16: 535 / 107, 32: 445 / 93, 128: 269 / -, none: 305 / 52; at 5 cm: no effect)
-  I->fast.cap0 = ((I->steps_max - 1) / 3 > 140) ? 8u : 0xFFFFFFFFu;
   const u64 want = static_cast<u64>(cap) * I->steps_max;
   const u64 limit = 0x7FFFFFF0ull;
   const u32 rcap = static_cast<u32>(std::min(want, limit));
@@ -1415,22 +1501,38 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   COX_TRY(alloc_sort_ws(&I->sort_rec, (I->piece_path || I->piece_sort) ? piece_cap : rcap));
   if (I->piece_sort) COX_TRY(dev_realloc(&I->scanws_p.block_sums, scan_num_blocks(piece_cap) + 2));
   if (I->method == COX_METHOD_FAST) {
-    COX_TRY(alloc_sort_ws(&I->sort_vis, rcap));
     FastState& X = I->fast;
     COX_TRY(dev_realloc(&X.fhash, cap));
     COX_TRY(dev_realloc(&X.fresh, cap));
     COX_TRY(dev_realloc(&X.rank, cap));
-    COX_TRY(dev_realloc(&X.cap, cap));
-    COX_TRY(dev_realloc(&X.reach[0], cap));
-    COX_TRY(dev_realloc(&X.reach[1], cap));
-    COX_TRY(dev_realloc(&X.vhash, rcap));
-    COX_TRY(dev_realloc(&X.vray, rcap));
-    COX_TRY(dev_realloc(&X.pos_of, rcap));
-    COX_TRY(dev_realloc(&X.eloc, rcap));
-    COX_TRY(dev_realloc(&X.sray, rcap));
-    COX_TRY(dev_realloc(&X.sstep, rcap));
-    COX_TRY(dev_realloc(&X.shash, rcap));
-    COX_TRY(dev_realloc(&X.tmax, rcap / kFastTile + 2));
+    COX_TRY(dev_realloc(&X.long_list, cap));
+    for (int k = 0; k < kFrameSets; ++k) {
+      COX_TRY(dev_realloc(&X.cap[k], cap));
+      COX_TRY(dev_realloc(&X.reach[k], cap));
+    }
+    // round 0: kFastCap0 list slots per point; round 1: the grown lists -- bounded (a frame whose lists do not fit is redone by
+    // the sequential kernel), not sized for "every ray walks to the sensor" as the uncapped lists of round 2 were (5 GB at 5 cm)
+    const u32 vcap0 = static_cast<u32>(std::min<u64>(static_cast<u64>(cap) * kFastCap0Max, 0xFFFFFFF0ull));
+    const u32 vcap1 = static_cast<u32>(std::min<u64>(rcap, std::max<u64>(static_cast<u64>(cap) * 64, 1ull << 24)));
+    auto alloc_vs = [&](VisitSet& V, u32 vcap) -> int {
+      for (int k = 0; k < 2; ++k) {
+        COX_TRY(dev_realloc(&V.key[k], vcap));
+        COX_TRY(dev_realloc(&V.val[k], vcap));
+      }
+      COX_TRY(dev_realloc(&V.vhash, vcap));
+      COX_TRY(dev_realloc(&V.shash, vcap));
+      COX_TRY(dev_realloc(&V.vray, vcap));
+      COX_TRY(dev_realloc(&V.pos_of, vcap));
+      COX_TRY(dev_realloc(&V.sinfo, vcap));
+      COX_TRY(dev_realloc(&V.voff, cap));
+      V.cap = vcap;
+      return COX_OK;
+    };
+    COX_TRY(alloc_vs(X.vs0[0], vcap0));
+    COX_TRY(alloc_vs(X.vs0[1], vcap0));
+    COX_TRY(alloc_vs(X.vs1, vcap1));
+    COX_TRY(alloc_sort_ws(&I->sort_vis, vcap0));
+    COX_TRY(alloc_sort_ws(&I->sort_vis1, vcap1));
   }
   const u32 need_scan = scan_num_blocks(cap) + 2;
   if (need_scan > I->scan_cap) {
@@ -1494,7 +1596,7 @@ static inline dim3 grid_for(u32 n, u32 block = 256, u32 cap = 0x7FFFFFFFu) { ret
 // classes whose regions are opened by the submission thread (stages B1 / B2; not for fast, which has none) take their
 // events from a pool of their own
 static inline int event_pool_of(const cox_integrator* I, int cls) {
-  return (I->submitter && (cls == COX_KC_APPLY || cls == COX_KC_TOUCH_EMIT || cls == COX_KC_RECORD_SORT)) ? 1 : 0;
+  return (I->submitter && (cls == COX_KC_APPLY || cls == COX_KC_TOUCH_EMIT || cls == COX_KC_RECORD_SORT || cls == COX_KC_FAST_SWEEPS || cls == COX_KC_FAST_ROUND1)) ? 1 : 0;
 }
 static thread_local u64 tl_frame_no = 0;  // the frame whose stages this thread is enqueueing (StageCtx::frame)
 struct TimedRegion {
@@ -1538,6 +1640,7 @@ struct StageCtx {
   RecordSet* S;
   int slot;
   u64 frame;  // frame number (which frames carry timing events)
+  const u32* n_dev = nullptr;  // the frame's point count when it is known on the device only (depth front end); n_points of the parameter block is then an upper bound
 };
 
 static LayerView layer_view(const cox_layer* Lh) {
@@ -1606,7 +1709,10 @@ static int stage_hash(const StageCtx& c, hipStream_t s) {
   FrameSet& F = *c.F;
   BundleSet& B = *c.B;
   const bool by_value = (I->method == COX_METHOD_MERGED) && !I->use_graphs;
-  if (!by_value) COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  if (!by_value) {
+    COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+    if (c.n_dev) hipLaunchKernelGGL(k_params_count, dim3(1), dim3(1), 0, s, F.d_params, c.n_dev);
+  }
   COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
   if (I->method == COX_METHOD_MERGED) {
     const u32 n = I->pcap;  // grids cover the capacity; the kernels stop at the frame's own point count
@@ -1616,8 +1722,8 @@ static int stage_hash(const StageCtx& c, hipStream_t s) {
       // that (rare) configuration keeps the memset; otherwise the frame cleans up after itself (k_bundle_clear)
       const bool self_clean = !I->cfg.enable_anti_grazing;
       if (!self_clean) COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
-      hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, F.fh_keys, F.fh_first, I->fh_cap - 1,
-                         B.pslot, F.cnt);
+      hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, c.n_dev, F.fh_keys, F.fh_first,
+                         I->fh_cap - 1, B.pslot, F.cnt);
       hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
       if (self_clean) hipLaunchKernelGGL(k_bundle_clear, grid_for(n), dim3(256), 0, s, F.d_params, B.pslot, F.fh_keys, F.fh_first);
     }
@@ -1814,7 +1920,7 @@ static int run_stage(int k, const StageCtx& c) {
   cox_integrator* I = c.I;
   hipStream_t s = stage_stream(I, k, c.slot);
   tl_frame_no = c.frame;
-  if (!I->use_graphs || I->profiling) return kStages[k](c, s);
+  if (!I->use_graphs || I->profiling || (k == 0 && c.n_dev)) return kStages[k](c, s);
   hipGraphExec_t& gx = I->graphs[k][c.slot];
   if (!gx) {
     hipGraph_t g = nullptr;
@@ -1840,14 +1946,27 @@ static int run_stage(int k, const StageCtx& c) {
   return COX_OK;
 }
 
-// ---- fast: one frame.  Everything runs on one stream; the relaxation of the early-termination rule (cox_fast.hpp) is
-// checked for convergence from the host every few sweeps, so unlike simple / merged this call is not fully asynchronous.
-static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
+// ---- fast: one frame = three chains, each on a stream of its own, each in frame order (cox_fast.hpp):
+//   front   (st[0], caller's thread)      start set -> ray list -> round-0 candidate lists (kFastCap0 steps per ray), sorted by slot;
+//                                         touches the start table and this frame's own buffers only
+//   solve   (st[1], submission thread)    relaxation of the observed set over the capped lists, whole walks for the rays that got
+//                                         through them, relaxation again, commit to the observed table; frame t + 1's solve needs
+//                                         the table frame t leaves, so this chain sets the frame rate
+//   update  (st[3], submission thread)    the record pipeline of `simple` over every ray's first reach[r] voxels
+// No host round trip anywhere: convergence, growth and overflow are decided on the device, the sweep launches of a round are
+// enqueued speculatively (they return at once behind a launch that moved nothing), and a frame whose relaxation did not settle
+// within them is redone by k_fast_sequential, exactly.
+struct FastJob {
+  FastFrame FF;
+  bool wipe_obs = false;  // ApproxHashSet::resetApproxSet reached its full_reset_threshold: the table is zeroed
+  int vs = 0;             // which round-0 visit set the front filled
+};
+static int fast_front(const StageCtx& c, FastJob* job) {
   cox_integrator* I = c.I;
   FrameSet& F = *c.F;
   BundleSet& B = *c.B;
-  RecordSet& S = *c.S;
   FastState& X = I->fast;
+  const hipStream_t s = I->st[0];
   // FastTsdfIntegrator::integratePointCloud: both sets are reset every clear_checks_every_n_frames frames;
   // ApproxHashSet::resetApproxSet bumps the offset and wipes the table every 10 000 resets
   if (++X.reset_counter >= I->cfg.clear_checks_every_n_frames) {
@@ -1857,104 +1976,100 @@ static int fast_frame(const StageCtx& c, hipStream_t s, hipStream_t s_back) {
       X.off_start = 0;
     }
     if (++X.off_obs >= kFastFullReset) {
-      COX_HIP(hipMemsetAsync(X.table_obs, 0, sizeof(u64) * kFastSlots, s));
+      job->wipe_obs = true;  // (on the solve's stream, between the previous frame's commit and this frame's sweeps)
       X.off_obs = 0;
     }
   }
   const FastFrame FF{X.off_start, X.off_obs, I->cfg.max_consecutive_ray_collisions};
-  const u32 n = I->pcap, vcap = I->rcap;
-  const dim3 gp = grid_for(n, 256, 4096), gv(2048), gr = grid_for(n, 256, 1024), gw(4096);  // gw: one wave per ray, grid-stride
-  COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
-  COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
-  COX_HIP(hipMemsetAsync(X.d_changed, 0, sizeof(u32) * kFastMaxSweeps, s));
-  // start set: sort the points by slot (21 key bits: slot + "not integrated"), compare neighbours
-  TimedRegion* t_fast = new TimedRegion(I, COX_KC_FAST_START, s);
-  hipLaunchKernelGGL(k_fast_points, gp, dim3(256), 0, s, F.d_params, FF, X.fhash, B.skey[0], B.sval[0], F.cnt);
-  const int pp = radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, kFastSlotBits + 1, false, 2, I->sort_pts, nullptr, s);
-  hipLaunchKernelGGL(k_fast_start_flags, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start, X.fresh);
-  hipLaunchKernelGGL(k_fast_start_commit, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start);
-  exclusive_scan_u32(X.fresh, X.rank, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
-  hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, X.cap, X.cap0, F.cnt);
-  delete t_fast;
-  t_fast = nullptr;
-  // Jacobi sweeps until one changes nothing.  (Capturing a batch into a HIP graph was measured: no gain, the sweeps are
-  // bound by their own dependent loads, not by launches.)
-  // sweeps between two looks at the "changed" flags.  Most frames settle within a handful of sweeps, the first frames of a
-  // stream need 14-18.  Measured on the benchmark stream (frames/s) with a blocking look per batch: 14+4: 1275, 8+2: 1503,
-  // 4+2: 1601, 2+1: 1564; with the look one batch behind (below): 4+2: 2317, 3+1: 2408, 4+1: 2525, 6+3: 2044
-  constexpr int kFirstBatch = 4, kNextBatch = 1;
-  int sweep = 0;  // sweeps enqueued (over all rounds)
-  FastVisits V{};
-  for (int round = 0;; ++round) {
-    // candidate visits: the first cap[r] voxels of every ray's walk, sorted by slot of the observed set
-    t_fast = new TimedRegion(I, COX_KC_FAST_VISITS, s);
-    exclusive_scan_u32(X.cap, F.rays.rec_off, &F.cnt->n_rays, n, n, &F.cnt->n_records, I->scanws_f, s);
-    if (I->small_axis_cap)
-      hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
-                         X.cap, round == 0 ? 1 : 0, vcap, F.cnt);
-    else
-      hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, X.vhash, S.rec_key[0], S.rec_ray[0], X.vray, X.reach[sweep & 1],
-                         X.cap, round == 0 ? 1 : 0, vcap, F.cnt);
-    const int vp = radix_sort_pairs<11>(S.rec_key[0], S.rec_ray[0], S.rec_key[1], S.rec_ray[1], &F.cnt->n_records, vcap, std::min<u32>(vcap, 1u << 21),
-                                        kFastSlotBits, false, 2, I->sort_vis, nullptr, s);
-    hipLaunchKernelGGL(k_fast_inverse, gv, dim3(256), 0, s, S.rec_ray[vp], X.vray, X.vhash, F.rays.rec_off, X.pos_of, X.sray, X.sstep, X.shash, F.cnt, vcap);
-    V = FastVisits{S.rec_key[vp], X.sray, X.sstep, X.shash, F.rays.rec_off, X.pos_of};
-    delete t_fast;
-    t_fast = new TimedRegion(I, COX_KC_FAST_SWEEPS, s);
-    const int round_first = sweep;
-    auto enqueue = [&](int first, int count) -> int {
-      for (int k = first; k < first + count; ++k) {
-        // (a round's first sweep always runs: the flag before it belongs to the previous round or to k_fast_grow_caps)
-        const u32* prev = (k > round_first) ? X.d_changed + (k - 1) : nullptr;
-        hipLaunchKernelGGL(k_fast_scan_tiles, gv, dim3(256), 0, s, V, X.reach[k & 1], X.eloc, X.tmax, F.cnt, vcap, prev);
-        hipLaunchKernelGGL(k_fast_sweep, gw, dim3(256), 0, s, V, I->cfg.max_consecutive_ray_collisions, X.cap, X.eloc, X.tmax, X.table_obs, X.reach[k & 1],
-                           X.reach[(k + 1) & 1], X.d_changed + k, F.cnt, vcap, prev);
-      }
-      COX_HIP(hipMemcpyAsync(X.h_changed + first, X.d_changed + first, sizeof(u32) * count, hipMemcpyDeviceToHost, s));
-      return COX_OK;
-    };
-    // The host looks at the "changed" flags one batch behind what it has enqueued: the next batch is already queued while it
-    // waits for the previous one's flags, so the GPU never idles for the round trip.  Sweeps that run after convergence
-    // reproduce the fixed point, so the (at most kNextBatch) speculative sweeps cost time but cannot change the result.
-    const int first_batch = (round == 0) ? kFirstBatch : 1;  // later rounds start from the previous round's fixed point
-    if (sweep + first_batch + kNextBatch + 1 > kFastMaxSweeps) return COX_ERR_INTERNAL;
-    COX_TRY(enqueue(sweep, first_batch));
-    COX_HIP(hipEventRecord(X.ev[0], s));
-    sweep += first_batch;
-    for (int k = 0;; ++k) {
-      const int checked_last = sweep - 1;  // last sweep of the batch whose flags event k carries
-      if (sweep + kNextBatch + 1 > kFastMaxSweeps) return COX_ERR_INTERNAL;  // never seen; the iteration is finite by construction
-      COX_TRY(enqueue(sweep, kNextBatch));
-      COX_HIP(hipEventRecord(X.ev[(k + 1) & 1], s));
-      sweep += kNextBatch;
-      COX_HIP(hipEventSynchronize(X.ev[k & 1]));
-      if (X.h_changed[checked_last] == 0) break;
-    }
-    delete t_fast;
-    t_fast = nullptr;
-    if (X.cap0 == 0xFFFFFFFFu) break;  // whole walks from the start: nothing to grow
-    // did a ray reach the end of its candidate list without stopping?  (flag in the next free slot of the sweep flags)
-    hipLaunchKernelGGL(k_fast_grow_caps, gr, dim3(256), 0, s, F.rays.nsteps, X.cap, X.reach[sweep & 1], X.reach[(sweep + 1) & 1], X.d_changed + sweep, F.cnt);
-    COX_HIP(hipMemcpyAsync(X.h_changed + sweep, X.d_changed + sweep, sizeof(u32), hipMemcpyDeviceToHost, s));
-    COX_HIP(hipStreamSynchronize(s));
-    const bool grew = X.h_changed[sweep] != 0;
-    sweep += 1;  // the slot is used up; keeps the parity bookkeeping simple: both reach buffers hold the same values here
-    if (!grew) break;
-  }
-  X.sweeps_total += static_cast<uint64_t>(sweep);
+  job->FF = FF;
+  job->vs = static_cast<int>(X.frames & 1u);
   X.frames += 1;
-  // the last enqueued sweep changed nothing: reach[sweep & 1] == reach[(sweep - 1) & 1], and eloc / tmax belong to it
-  const u32* reach = X.reach[sweep & 1];
-  hipLaunchKernelGGL(k_fast_obs_commit, gv, dim3(256), 0, s, V, reach, X.eloc, X.tmax, X.table_obs, F.cnt, vcap);
+  VisitSet& V0 = X.vs0[job->vs];
+  if (V0.used) COX_HIP(hipStreamWaitEvent(s, V0.done, 0));  // the solve of frame t-2 is done with this visit set
+  const u32 n = I->pcap;
+  const dim3 gp = grid_for(n, 256, 4096), gw(4096);  // gw: one wave per ray, grid-stride
+  COX_HIP(hipMemcpyAsync(F.d_params, &I->h_params[c.slot], sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  if (c.n_dev) hipLaunchKernelGGL(k_params_count, dim3(1), dim3(1), 0, s, F.d_params, c.n_dev);
+  COX_HIP(hipMemsetAsync(F.cnt, 0, sizeof(Counters), s));
+  {
+    // start set: sort the points by slot (21 key bits: slot + "not integrated"), compare neighbours
+    TimedRegion t(I, COX_KC_FAST_START, s);
+    hipLaunchKernelGGL(k_fast_points, gp, dim3(256), 0, s, F.d_params, FF, X.fhash, B.skey[0], B.sval[0], F.cnt);
+    const int pp = radix_sort_pairs<11>(B.skey[0], B.sval[0], B.skey[1], B.sval[1], &F.d_params->n_points, n, n, kFastSlotBits + 1, false, 2, I->sort_pts, nullptr, s);
+    hipLaunchKernelGGL(k_fast_start_flags, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start, X.fresh);
+    hipLaunchKernelGGL(k_fast_start_commit, gp, dim3(256), 0, s, F.d_params, B.skey[pp], B.sval[pp], X.fhash, X.table_start);
+    exclusive_scan_u32(X.fresh, X.rank, &F.d_params->n_points, n, n, &F.cnt->n_rays, I->scanws_a, s);
+    hipLaunchKernelGGL(k_fast_rays, gp, dim3(256), 0, s, F.d_params, X.fresh, X.rank, F.rays, X.cap[c.slot], X.reach[c.slot], X.cap0, V0.cap, F.cnt);
+  }
+  {
+    // round 0's candidate visits: the first kFastCap0 voxels of every ray's walk, sorted by slot of the observed set (they depend on
+    // this frame's rays only, so they are made here, beside the previous frame's solve)
+    TimedRegion t(I, COX_KC_FAST_VISITS, s);
+    if (I->small_axis_cap)
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V0.vhash, V0.key[0], V0.val[0], V0.vray, V0.voff, X.cap[c.slot],
+                         X.cap0, V0.cap, F.cnt);
+    else
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V0.vhash, V0.key[0], V0.val[0], V0.vray, V0.voff, X.cap[c.slot],
+                         X.cap0, V0.cap, F.cnt);
+    V0.sorted = radix_sort_pairs<11>(V0.key[0], V0.val[0], V0.key[1], V0.val[1], &F.cnt->fast.n_visits[0], V0.cap, std::min<u32>(V0.cap, 1u << 19), kFastSlotBits + 1,
+                                     false, 2, I->sort_vis, nullptr, s);
+    hipLaunchKernelGGL(k_fast_inverse, dim3(512), dim3(256), 0, s, V0.key[V0.sorted], V0.val[V0.sorted], V0.vray, V0.vhash, V0.voff, V0.pos_of, V0.sinfo, V0.shash,
+                       &F.cnt->fast.n_visits[0], V0.cap);
+  }
+  return COX_OK;
+}
+static inline FastVisits fast_view(const VisitSet& V) { return FastVisits{V.key[V.sorted], V.sinfo, V.shash, V.voff, V.pos_of}; }
+static int fast_solve(const StageCtx& c, const FastJob& job) {
+  cox_integrator* I = c.I;
+  FrameSet& F = *c.F;
+  FastState& X = I->fast;
+  const hipStream_t s = I->st[1];
+  const FastFrame FF = job.FF;
+  VisitSet& V0 = X.vs0[job.vs];
+  VisitSet& V1 = X.vs1;
+  u32* cap = X.cap[c.slot];
+  u32* reach = X.reach[c.slot];
+  FastCtl* ctl = &F.cnt->fast;
+  const u32* n_rays = &F.cnt->n_rays;
+  const int mc = I->cfg.max_consecutive_ray_collisions;
+  const dim3 gr = grid_for(I->pcap, 256, 1024), gw(4096);
+  if (job.wipe_obs) COX_HIP(hipMemsetAsync(X.table_obs, 0, sizeof(u64) * kFastSlots, s));
+  {
+    TimedRegion t(I, COX_KC_FAST_SWEEPS, s);
+    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V0), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, 0, X.cap0,
+                       X.long_list, n_rays, X.fences);
+  }
+  {
+    // round 1 (every kernel returns at once when round 0 left nobody at the end of a capped list): whole walks for those rays, all
+    // lists sorted again, relaxation from round 0's fixed point
+    TimedRegion t(I, COX_KC_FAST_ROUND1, s);
+    hipLaunchKernelGGL(k_fast_grow, gr, dim3(256), 0, s, F.rays.nsteps, cap, reach, ctl, X.cap1, X.long_list, n_rays);
+    if (I->pcap <= (1u << 15)) {
+      hipLaunchKernelGGL(k_fast_scan_caps, dim3(1), dim3(1024), 0, s, cap, V1.voff, ctl, I->pcap, V1.cap);
+    } else {  // (rays by the hundred thousand: the three-launch scan; it covers scan_n rays, none without growth)
+      exclusive_scan_u32(cap, V1.voff, &ctl->scan_n, I->pcap, I->pcap, &ctl->n_visits[1], I->scanws_f, s);
+      hipLaunchKernelGGL(k_fast_scan_caps_done, dim3(1), dim3(1), 0, s, ctl, V1.cap);
+    }
+    if (I->small_axis_cap)
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V1.vhash, V1.key[0], V1.val[0], V1.vray, V1.voff, cap, 0u, V1.cap,
+                         F.cnt);
+    else
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V1.vhash, V1.key[0], V1.val[0], V1.vray, V1.voff, cap, 0u, V1.cap,
+                         F.cnt);
+    V1.sorted = radix_sort_pairs<11>(V1.key[0], V1.val[0], V1.key[1], V1.val[1], &ctl->n_visits[1], V1.cap, std::min<u32>(V1.cap, 1u << 19), kFastSlotBits + 1, false, 2,
+                                     I->sort_vis1, nullptr, s);
+    hipLaunchKernelGGL(k_fast_inverse, dim3(512), dim3(256), 0, s, V1.key[V1.sorted], V1.val[V1.sorted], V1.vray, V1.vhash, V1.voff, V1.pos_of, V1.sinfo, V1.shash,
+                       &ctl->n_visits[1], V1.cap);
+    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V1), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, 1, X.cap1,
+                       X.long_list, n_rays, X.fences);
+  }
+  // (the relaxation packs (ray, step) into one word: a configuration whose walks or ray counts do not fit takes the sequential kernel)
+  const bool packed_ok = I->steps_max <= kFastStepMask && I->pcap <= (1u << (32 - kFastStepBits));
+  hipLaunchKernelGGL(k_fast_sequential, dim3(1), dim3(64), 0, s, F.d_params, FF, F.rays, X.table_obs, reach, ctl, (X.force_sequential || !packed_ok) ? 1 : 0, n_rays);
+  hipLaunchKernelGGL(k_fast_obs_commit, dim3(512), dim3(256), 0, s, fast_view(V0), fast_view(V1), reach, X.table_obs, ctl, V0.cap, V1.cap, X.d_stats);
   hipLaunchKernelGGL(k_fast_finish, gr, dim3(256), 0, s, F.rays, reach, F.cnt);
-  // updates: the record pipeline of `simple` (records partitioned by tile, replayed in visiting order) -- on the second
-  // stream, so that the next frame's start set / visits / sweeps (which only touch the two tables and this frame's own
-  // buffers) run beside it
-  COX_HIP(hipEventRecord(I->ev_a2, s));
-  COX_HIP(hipStreamWaitEvent(s_back, I->ev_a2, 0));
-  COX_TRY(run_stage(3, c));  // touch / emit, record partition, apply on st[3] == st[4] == st[5] (== s_back); replayed as
-  COX_TRY(run_stage(4, c));  // captured graphs when COX_GRAPH is set
-  COX_TRY(run_stage(5, c));
+  COX_HIP(hipEventRecord(V0.done, s));
+  V0.used = true;
   return COX_OK;
 }
 
@@ -1998,8 +2113,17 @@ static int follow_layer(cox_integrator* I) {
   return COX_OK;
 }
 
+// Ordering of one frame's inputs against whoever produces them (the engine's own input stream: staged host buffers, converted depth
+// images), besides the caller's stream of cox_integrator_set_input_stream:
+//   ready      the frame's first stage waits for it                 consumed   recorded once the inputs have been read for the last time
+//   n_dev      the point count, where only the device knows it (n is then an upper bound)
+struct FrameInput {
+  hipEvent_t ready = nullptr, consumed = nullptr;
+  const u32* n_dev = nullptr;
+};
 // enqueue the whole frame; xyz / rgba are device pointers that must stay valid until the frame's stage A2 is done
-static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace, bool caller_waits = false) {
+static int integrate_device(cox_integrator* I, const float T[7], const float* xyz, const uint8_t* rgba, u32 n, int freespace, bool caller_waits = false,
+                            const FrameInput& in = FrameInput()) {
   cox_layer* Lh = I->layer;
   struct HostTimer {
     cox_integrator* I;
@@ -2021,14 +2145,16 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   I->last = cox_frame_stats{};
   I->last.n_points = n;
   I->last_has_counts = false;
-  if (n == 0) return COX_OK;
+  // (an empty cloud still resets the fast integrator's two sets, as FastTsdfIntegrator::integratePointCloud does before it looks at a point)
+  if (n == 0 && I->method != COX_METHOD_FAST) return COX_OK;
   I->frame_no += 1;
   const int slot = static_cast<int>(I->frame_no % kFrameSets);
   FrameSet& F = I->fs[slot];
   BundleSet& B = I->bs[slot % kStageSets];
   RecordSet& S = I->rs[slot % kStageSets];
-  const StageCtx ctx{I, &F, &B, &S, slot, I->frame_no};
+  const StageCtx ctx{I, &F, &B, &S, slot, I->frame_no, in.n_dev};
   tl_frame_no = I->frame_no;
+  I->last_count_on_device = in.n_dev != nullptr;
   // the pinned parameter slot is free once the copy of the frame that used it last (t-4) has run
   if (F.used) {
     const auto w0 = std::chrono::steady_clock::now();
@@ -2043,23 +2169,48 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
     COX_HIP(hipStreamWaitEvent(stage_stream(I, 0, slot), I->ev_producer, 0));
   }
-  if (I->method == COX_METHOD_FAST) {  // front (sets, sweeps) on st[0], record stage on st[2], see fast_frame
+  if (in.ready) COX_HIP(hipStreamWaitEvent(stage_stream(I, 0, slot), in.ready, 0));
+  if (I->method == COX_METHOD_FAST) {  // front on st[0] (this thread), solve on st[1] and update on st[3] (submission thread): fast_front / fast_solve
     if (F.used) COX_HIP(hipStreamWaitEvent(I->st[0], F.done, 0));  // frame t-6 is done with this frame set
-    if (S.used) COX_HIP(hipStreamWaitEvent(I->st[0], S.done, 0));  // frame t-3's record stage is done with this record set (the visit sort borrows it)
-    COX_TRY(fast_frame(ctx, I->st[0], I->st[3]));
+    FastJob job;
+    COX_TRY(fast_front(ctx, &job));
     COX_HIP(hipEventRecord(F.params_copied, I->st[0]));
+    COX_HIP(hipEventRecord(F.hand[0], I->st[0]));
     if (I->has_producer) {  // the inputs are read by the front only
       COX_HIP(hipEventRecord(I->ev_inputs_read, I->st[0]));
       COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
     }
-    COX_HIP(hipEventRecord(F.done, I->st[5]));
-    COX_HIP(hipEventRecord(S.done, I->st[5]));
-    COX_HIP(hipEventRecord(Lh->last_write, I->st[5]));
-    Lh->has_write = true;
-    F.used = true;
-    S.used = true;
-    I->last_has_counts = true;
+    if (in.consumed) COX_HIP(hipEventRecord(in.consumed, I->st[0]));
     COX_HIP(hipGetLastError());
+    auto back = [ctx, job]() -> int {
+      cox_integrator* I = ctx.I;
+      FrameSet& F = *ctx.F;
+      RecordSet& S = *ctx.S;
+      cox_layer* Lh = I->layer;
+      tl_frame_no = ctx.frame;
+      COX_HIP(hipStreamWaitEvent(I->st[1], F.hand[0], 0));
+      COX_TRY(fast_solve(ctx, job));
+      COX_HIP(hipEventRecord(F.hand[2], I->st[1]));
+      COX_HIP(hipStreamWaitEvent(I->st[3], F.hand[2], 0));
+      COX_TRY(run_stage(3, ctx));  // touch / emit, record partition, apply on st[3] == st[4] == st[5]
+      COX_TRY(run_stage(4, ctx));
+      COX_TRY(run_stage(5, ctx));
+      COX_HIP(hipEventRecord(F.done, I->st[5]));
+      COX_HIP(hipEventRecord(S.done, I->st[5]));
+      COX_HIP(hipEventRecord(Lh->last_write, I->st[5]));
+      Lh->has_write = true;
+      F.used = true;
+      S.used = true;
+      COX_HIP(hipGetLastError());
+      return COX_OK;
+    };
+    if (I->submitter && !caller_waits) {
+      I->submitter->post(back);
+    } else {
+      if (I->submitter) I->submitter->wait_outstanding(0);
+      COX_TRY(back());
+    }
+    I->last_has_counts = true;
     return COX_OK;
   }
   // stage k + 1 of a frame follows stage k: in stream order, or behind the frame slot's hand-over event when on another stream
@@ -2085,6 +2236,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     COX_HIP(hipEventRecord(I->ev_inputs_read, s_m));
     COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
   }
+  if (in.consumed) COX_HIP(hipEventRecord(in.consumed, s_m));
   COX_HIP(hipGetLastError());
   // T, R, U (layer update): on the submission thread when there is one
   auto stage_b = [ctx, chain]() -> int {
@@ -2121,6 +2273,11 @@ static int fold_counters(cox_integrator* I) {
   if (!I->last_has_counts) return COX_OK;
   Counters& c = I->h_ring[I->frame_no % kStatRing];
   COX_HIP(hipMemcpy(&c, I->fs[I->frame_no % kFrameSets].cnt, sizeof(Counters), hipMemcpyDeviceToHost));
+  if (I->last_count_on_device) {  // (depth front end: the host never saw the frame's point count)
+    u32 np = 0;
+    COX_HIP(hipMemcpy(&np, &I->fs[I->frame_no % kFrameSets].d_params->n_points, sizeof(u32), hipMemcpyDeviceToHost));
+    I->last.n_points = np;
+  }
   u64 sh[5] = {0, 0, 0, 0, 0};
   u32 max_bundle = 0, max_run = 0;
   for (int s = 0; s < 64; ++s) {
@@ -2256,7 +2413,6 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     const int v = std::atoi(e);  // ("4s" parses as 4)
     if (v == 2 || v == 4 || v == 6) I->n_streams = v;
   }
-  if (method == COX_METHOD_FAST) I->n_streams = 2;  // front | record stage (graphs, if enabled, cover the record stage only)
   {
     // stage -> stream: 6: one each; 4: H P | M | T R | U; 2: H P M | T R U.  Equal streams are adjacent.
     // Default (four streams): H P M | H P M | T R | U -- ray generation depends on the frame's input only, so two frames run
@@ -2265,12 +2421,14 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     // In between -- the piece partition at moderate ray lengths (2 cm: 5 * 10^6 records per frame, the layer update three times
     // the ray generation, its kernels still latency-bound) -- the four streams go to H P M | T | R | U instead: 2 456 -> 2 910
     // frames/s at 2 cm; at 1 cm (2.5 * 10^7 records, throughput-bound kernels) that map loses 7 %, so it keeps the default.
-    static const int kMap[5][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 1, 1, 2}, {0, 0, 0, 1, 2, 3}};
+    // fast: front | solve | update (fast_front / fast_solve): st[0] | st[1] == st[2] | st[3] == st[4] == st[5]; COX_FAST_STREAMS=1 puts
+    // all three on one stream (round 2's arrangement).
+    static const int kMap[6][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 1, 1, 2}, {0, 0, 0, 1, 2, 3}, {0, 1, 1, 2, 2, 2}};
     const bool chosen = std::getenv("COX_STREAM_MAP") || std::getenv("COX_STREAMS");
     const bool update_heavy = !chosen && method == COX_METHOD_MERGED && I->piece_sort && (max_steps_per_ray(I) - 1) / 3 <= 200;
     const bool parity = I->n_streams == 4 && method != COX_METHOD_FAST && !std::getenv("COX_STREAM_MAP") && !update_heavy &&
                         !(std::getenv("COX_STREAMS") && std::string(std::getenv("COX_STREAMS")) == "4s");  // COX_STREAMS=4s: the staged map H P | M | T R | U
-    const int* map = kMap[update_heavy ? 4 : parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    const int* map = kMap[method == COX_METHOD_FAST ? 5 : update_heavy ? 4 : parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
     if (parity && st == COX_OK && hipStreamCreateWithFlags(&I->st_alt, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
     int custom[kNumStages];
     if (const char* e = std::getenv("COX_STREAM_MAP")) {  // experiments: six digits, stage -> stream, equal streams adjacent (e.g. 012334)
@@ -2281,27 +2439,34 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
       }
       if (ok && method != COX_METHOD_FAST) map = custom;
     }
-    // fast: its front is a chain of short sweeps with host round trips in between, and the record stage of the previous frame
-    // running beside it slows every one of them: measured with 16 hardware queues, one stream 2 393 frames/s, two streams
-    // 1 898, two streams with the front at high priority 1 952 (with the runtime's default of 4 queues the two streams mostly
-    // shared a queue and the question did not arise).  One stream it is; COX_FAST_STREAMS=2 / 3 select the other two.
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    const int fast_mode = std::getenv("COX_FAST_STREAMS") ? std::atoi(std::getenv("COX_FAST_STREAMS")) : 1;  // 1: one stream, 2: priorities, 3: equal priorities
+    const int fast_mode = std::getenv("COX_FAST_STREAMS") ? std::atoi(std::getenv("COX_FAST_STREAMS")) : 3;  // 1: one stream, otherwise three
+    if (method == COX_METHOD_FAST) {
+      I->n_streams = fast_mode == 1 ? 1 : 3;
+      if (const char* e = std::getenv("COX_FAST_FENCE")) I->fast.fences = std::atoi(e);
+      if (const char* e = std::getenv("COX_FAST_GROUPS")) I->fast.relax_groups = static_cast<u32>(std::min(256, std::max(8, std::atoi(e))));
+      I->fast.force_sequential = std::getenv("COX_FAST_SEQUENTIAL") && std::atoi(std::getenv("COX_FAST_SEQUENTIAL")) != 0;
+      if (const char* e = std::getenv("COX_FAST_CAP")) {  // candidate steps per ray: "cap0" or "cap0,cap1"
+        int a = 0, b = 0;
+        const int got = std::sscanf(e, "%d,%d", &a, &b);
+        if (got >= 1 && (a == 8 || a == 16 || a == 32)) I->fast.cap0 = static_cast<u32>(a);  // (lanes per ray in the relaxation: a divisor of the wave)
+        I->fast.cap1 = std::max<u32>(I->fast.cap1, I->fast.cap0);
+        if (got >= 2 && (b == 8 || b == 16 || b == 32) && static_cast<u32>(b) >= I->fast.cap0) I->fast.cap1 = static_cast<u32>(b);
+      }
+    }
     hipStream_t made[kNumStages] = {};
     for (int k = 0; k < kNumStages; ++k) {
       int m = map[k];
       if (method == COX_METHOD_FAST && fast_mode == 1) m = 0;
-      if (!made[m] && st == COX_OK) {
-        const int prio = (method == COX_METHOD_FAST && fast_mode == 2) ? (m == 0 ? prio_greatest : prio_least) : 0;
-        const hipError_t e = (method == COX_METHOD_FAST && fast_mode == 2) ? hipStreamCreateWithPriority(&made[m], hipStreamNonBlocking, prio)
-                                                                             : hipStreamCreateWithFlags(&made[m], hipStreamNonBlocking);
-        if (e != hipSuccess) st = COX_ERR_NO_DEVICE;
-      }
+      if (!made[m] && st == COX_OK && hipStreamCreateWithFlags(&made[m], hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
       I->st[k] = made[m];
     }
   }
   ev(&I->ev_a2);
+  for (int k = 0; k < kStageSets; ++k) {
+    if (st == COX_OK && hipEventCreateWithFlags(&I->in_ready[k], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
+    ev(&I->in_free[k]);
+  }
+  if (st == COX_OK && hipStreamCreateWithFlags(&I->st_in, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
   ev(&I->ev_producer);
   ev(&I->ev_inputs_read);
   I->layer_generation = layer->generation;
@@ -2336,19 +2501,17 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_params), sizeof(FrameParams) * kFrameSets, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
-  if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_depth_n), sizeof(u32), hipHostMallocDefault) != hipSuccess) st = COX_ERR_OUT_OF_MEMORY;
-  if (st == COX_OK) st = dev_realloc(&I->d_depth_n, 1);
+  if (st == COX_OK) st = dev_realloc(&I->d_depth_n, kStageSets);
   if (st == COX_OK && method == COX_METHOD_FAST) {
     FastState& X = I->fast;
     st = dev_realloc(&X.table_start, kFastSlots);
     if (st == COX_OK) st = dev_realloc(&X.table_obs, kFastSlots);
-    if (st == COX_OK) st = dev_realloc(&X.d_changed, kFastMaxSweeps);
-    if (st == COX_OK && (hipMemset(X.table_start, 0, sizeof(u64) * kFastSlots) != hipSuccess || hipMemset(X.table_obs, 0, sizeof(u64) * kFastSlots) != hipSuccess))
+    if (st == COX_OK) st = dev_realloc(&X.d_stats, 8);
+    if (st == COX_OK && (hipMemset(X.table_start, 0, sizeof(u64) * kFastSlots) != hipSuccess || hipMemset(X.table_obs, 0, sizeof(u64) * kFastSlots) != hipSuccess ||
+                         hipMemset(X.d_stats, 0, sizeof(u32) * 8) != hipSuccess))
       st = COX_ERR_NO_DEVICE;
-    if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&X.h_changed), sizeof(u32) * kFastMaxSweeps, hipHostMallocDefault) != hipSuccess)
-      st = COX_ERR_OUT_OF_MEMORY;
-    ev(&X.ev[0]);
-    ev(&X.ev[1]);
+    ev(&X.vs0[0].done);
+    ev(&X.vs0[1].done);
   }
   if (st == COX_OK) {
     memset(I->h_ring, 0, sizeof(Counters) * kStatRing);
@@ -2362,7 +2525,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     cox_integrator_destroy(I);
     return st;
   }
-  if (method != COX_METHOD_FAST && !(std::getenv("COX_SUBMIT_THREAD") && std::atoi(std::getenv("COX_SUBMIT_THREAD")) == 0)) {
+  if (!(std::getenv("COX_SUBMIT_THREAD") && std::atoi(std::getenv("COX_SUBMIT_THREAD")) == 0)) {
     I->submitter = new (std::nothrow) Submitter();
     if (I->submitter) {
       I->submitter->device = layer->device;
@@ -2416,20 +2579,26 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   if (I->timeline_ref) (void)hipEventDestroy(I->timeline_ref);
   if (I->timeline) fclose(I->timeline);
   std::vector<void*> ptrs = {I->own_xyz[0], I->own_xyz[1], I->own_xyz[2], I->own_rgba[0], I->own_rgba[1], I->own_rgba[2], I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_pts_alt.counts, I->sort_pts_alt.totals, I->sort_rec.counts,
-                             I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
+                             I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->sort_vis1.counts, I->sort_vis1.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
                              I->scanws_f.block_sums, I->scanws_p.block_sums, I->scanws_h.block_sums};
+  std::vector<hipEvent_t> events = {I->ev_a2, I->ev_producer, I->ev_inputs_read};
   {
     FastState& X = I->fast;
-    for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.vhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs),
-                    static_cast<void*>(X.fresh), static_cast<void*>(X.rank), static_cast<void*>(X.cap), static_cast<void*>(X.vray), static_cast<void*>(X.sray), static_cast<void*>(X.sstep), static_cast<void*>(X.shash), static_cast<void*>(X.pos_of), static_cast<void*>(X.eloc),
-                    static_cast<void*>(X.tmax), static_cast<void*>(X.reach[0]), static_cast<void*>(X.reach[1]),
-                    static_cast<void*>(X.d_changed)})
+    for (void* q : {static_cast<void*>(X.fhash), static_cast<void*>(X.table_start), static_cast<void*>(X.table_obs), static_cast<void*>(X.fresh),
+                    static_cast<void*>(X.rank), static_cast<void*>(X.d_stats), static_cast<void*>(X.long_list)})
       ptrs.push_back(q);
-    if (X.h_changed) (void)hipHostFree(X.h_changed);
-    for (hipEvent_t e : X.ev)
-      if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < kFrameSets; ++k) {
+      ptrs.push_back(X.cap[k]);
+      ptrs.push_back(X.reach[k]);
+    }
+    for (VisitSet* V : {&X.vs0[0], &X.vs0[1], &X.vs1}) {
+      for (void* q : {static_cast<void*>(V->key[0]), static_cast<void*>(V->key[1]), static_cast<void*>(V->val[0]), static_cast<void*>(V->val[1]),
+                      static_cast<void*>(V->vhash), static_cast<void*>(V->shash), static_cast<void*>(V->vray), static_cast<void*>(V->pos_of),
+                      static_cast<void*>(V->sinfo), static_cast<void*>(V->voff)})
+        ptrs.push_back(q);
+      events.push_back(V->done);
+    }
   }
-  std::vector<hipEvent_t> events = {I->ev_a2, I->ev_producer, I->ev_inputs_read};
   for (FrameSet& F : I->fs) {
     const RayArrays& R = F.rays;
     for (void* p : {static_cast<void*>(R.px), static_cast<void*>(R.py), static_cast<void*>(R.pz), static_cast<void*>(R.w), static_cast<void*>(R.color),
@@ -2461,7 +2630,13 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
-  if (I->h_depth_n) (void)hipHostFree(I->h_depth_n);
+  for (int k = 0; k < kStageSets; ++k) {
+    if (I->pin_xyz[k]) (void)hipHostFree(I->pin_xyz[k]);
+    if (I->pin_rgba[k]) (void)hipHostFree(I->pin_rgba[k]);
+    if (I->in_ready[k]) (void)hipEventDestroy(I->in_ready[k]);
+    if (I->in_free[k]) (void)hipEventDestroy(I->in_free[k]);
+  }
+  if (I->st_in) (void)hipStreamDestroy(I->st_in);
   if (I->h_params) (void)hipHostFree(I->h_params);
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
@@ -2488,21 +2663,105 @@ int cox_integrate_points_ex(cox_integrator_t* I, const float T_G_C[7], const flo
   return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 1);
 }
 
+// Host buffers -> staging set k of the frame about to be enqueued, on the input stream, without waiting for anything but the
+// staging set itself: the copy of frame t + 1 runs beside the kernels of frame t.  Pageable memory goes through a pinned bounce
+// buffer (one CPU copy; the caller's buffer is free again when the call returns), pinned memory is copied from directly.
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  const hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+static int stage_host_inputs(cox_integrator* I, int k, const float* xyz, const uint8_t* rgba, u32 n, FrameInput* in) {
+  // the staging set is free once the frame that used it three frames ago has read it for the last time; that frame's stages
+  // H .. M are enqueued by the caller's thread, so the event is recorded by now
+  if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(I->st_in, I->in_free[k], 0));
+  const bool pinned = host_pointer_is_pinned(xyz) && (!rgba || host_pointer_is_pinned(rgba));
+  const float* src_xyz = xyz;
+  const uint8_t* src_rgba = rgba;
+  if (!pinned) {
+    if (I->pin_cap < I->pcap) {
+      COX_TRY(sync_all(I));
+      for (int q = 0; q < kStageSets; ++q) {
+        if (I->pin_xyz[q]) (void)hipHostFree(I->pin_xyz[q]);
+        if (I->pin_rgba[q]) (void)hipHostFree(I->pin_rgba[q]);
+        I->pin_xyz[q] = nullptr;
+        I->pin_rgba[q] = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&I->pin_xyz[q]), sizeof(float) * 3 * I->pcap, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&I->pin_rgba[q]), 4ull * I->pcap, hipHostMallocDefault) != hipSuccess) {
+          (void)hipGetLastError();
+          I->pin_cap = 0;
+          return COX_ERR_OUT_OF_MEMORY;
+        }
+      }
+      I->pin_cap = I->pcap;
+    }
+    // the bounce buffer's previous copy (three frames ago) has left it: in_ready[k] was recorded behind that copy
+    if (I->in_used[k]) COX_HIP(hipEventSynchronize(I->in_ready[k]));
+    memcpy(I->pin_xyz[k], xyz, sizeof(float) * 3 * n);
+    if (rgba) memcpy(I->pin_rgba[k], rgba, 4ull * n);
+    src_xyz = I->pin_xyz[k];
+    src_rgba = rgba ? I->pin_rgba[k] : nullptr;
+  }
+  COX_HIP(hipMemcpyAsync(I->own_xyz[k], src_xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st_in));
+  if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], src_rgba, 4ull * n, hipMemcpyHostToDevice, I->st_in));
+  COX_HIP(hipEventRecord(I->in_ready[k], I->st_in));
+  I->in_used[k] = true;
+  in->ready = I->in_ready[k];
+  in->consumed = I->in_free[k];
+  return COX_OK;
+}
+
 int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
   COX_ENTRY_NO_DRAIN();
   if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
   COX_HIP(hipSetDevice(I->layer->device));
   if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
-  COX_TRY(sync_all(I));  // the staging buffers may still feed an earlier frame
+  if (I->submitter) I->submitter->wait_outstanding(0);
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);  // the bundle set of the frame about to be enqueued
-  const hipStream_t s_in = stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets));
-  if (n) {
-    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, s_in));
-    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, s_in));
+  FrameInput in;
+  if (n) {  // synchronous call: copied straight from the caller's buffers (the runtime stages pageable memory itself), the call returns after the frame
+    if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(I->st_in, I->in_free[k], 0));
+    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st_in));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, I->st_in));
+    COX_HIP(hipEventRecord(I->in_ready[k], I->st_in));
+    I->in_used[k] = true;
+    in.ready = I->in_ready[k];
+    in.consumed = I->in_free[k];
   }
-  COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, true));
+  COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, true, in));
   return integrator_finish(I);
+}
+
+int cox_integrate_points_async(cox_integrator_t* I, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace) {
+  COX_ENTRY_NO_DRAIN();
+  if (!I || !T_G_C || (n && !xyz) || n > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  COX_HIP(hipSetDevice(I->layer->device));
+  if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
+  COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
+  if (I->submitter) I->submitter->wait_outstanding(1);
+  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
+  FrameInput in;
+  if (n) COX_TRY(stage_host_inputs(I, k, xyz, rgba, static_cast<u32>(n), &in));
+  // (the staging buffers are the engine's own: no ordering against the caller's stream for them)
+  const bool producer = I->has_producer;
+  I->has_producer = false;
+  const int st = integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, false, in);
+  I->has_producer = producer;
+  return st;
+}
+
+int cox_integrator_wait_inputs(cox_integrator_t* I) {
+  COX_ENTRY_NO_DRAIN();
+  if (!I) return COX_ERR_INVALID_ARG;
+  if (I->proj) return COX_OK;  // (the projective integrator's host entry point is synchronous)
+  COX_HIP(hipSetDevice(I->layer->device));
+  if (I->st_in) COX_HIP(hipStreamSynchronize(I->st_in));
+  return COX_OK;
 }
 
 int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4]) {
@@ -2512,32 +2771,35 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   COX_HIP(hipSetDevice(I->layer->device));
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
-  // Frames stay in flight: the point list goes to the staging set of the frame's bundle set (read by its stages H .. M; the
-  // frame that used the set three frames ago is waited for in stream order), and the only host wait is for the point count.
+  // Frames stay in flight and nothing comes back to the host: the point list goes to the staging set of the frame's bundle set
+  // (read by its stages H .. M), converted on the engine's input stream, and the point count -- which the "mixed" visiting order
+  // is a function of -- stays in device memory: the frame's first kernel takes it from there (k_bundle_insert / k_params_count).
   if (I->submitter) I->submitter->wait_outstanding(1);
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
-  hipStream_t s = stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets));  // the frame's ray-generation stream
-  if (I->bs[k].used && (I->st_alt || I->st[0] != I->st[2])) COX_HIP(hipStreamWaitEvent(s, I->bs[k].done, 0));
+  const hipStream_t s = I->st_in;
+  if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s, I->in_free[k], 0));
   if (I->has_producer) {  // the images were written on the caller's stream
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
     COX_HIP(hipStreamWaitEvent(s, I->ev_producer, 0));
   }
-  hipLaunchKernelGGL(k_depth_flags, grid_for(n), dim3(256), 0, s, depth_dev, n, I->depth_flag);
-  exclusive_scan_u32(I->depth_flag, I->depth_flag, nullptr, n, n, I->d_depth_n, I->scanws_d, s);
-  hipLaunchKernelGGL(k_depth_points, grid_for(n), dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz[k],
-                     I->own_rgba[k]);
+  const dim3 gt(std::max<u32>(1, (n + kDepthTile - 1) / kDepthTile));
+  hipLaunchKernelGGL(k_depth_count, gt, dim3(256), 0, s, depth_dev, n, I->depth_flag);
+  hipLaunchKernelGGL(k_depth_points, gt, dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz[k], I->own_rgba[k],
+                     I->d_depth_n + k);
   if (I->has_producer) {  // the images are not read after this: later work on the caller's stream may overwrite / free them
     COX_HIP(hipEventRecord(I->ev_inputs_read, s));
     COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
   }
-  // the point count feeds the "mixed" visiting order, which is a function of N: it has to reach the host
-  COX_HIP(hipMemcpyAsync(I->h_depth_n, I->d_depth_n, sizeof(u32), hipMemcpyDeviceToHost, s));
-  COX_HIP(hipStreamSynchronize(s));
-  const u32 n_pts = *I->h_depth_n;
+  COX_HIP(hipEventRecord(I->in_ready[k], s));
+  I->in_used[k] = true;
+  FrameInput in;
+  in.ready = I->in_ready[k];
+  in.consumed = I->in_free[k];
+  in.n_dev = I->d_depth_n + k;
   // (the staging buffers are the engine's own: no producer ordering for them)
   const bool producer = I->has_producer;
   I->has_producer = false;
-  const int st = integrate_device(I, T_G_C, I->own_xyz[k], I->own_rgba[k], n_pts, 0);
+  const int st = integrate_device(I, T_G_C, I->own_xyz[k], I->own_rgba[k], n, 0, false, in);
   I->has_producer = producer;
   return st;
 }
@@ -2646,6 +2908,21 @@ int cox_integrator_host_time(cox_integrator_t* I, double* ms_total, uint64_t* fr
     I->host_wait_ns = 0;
     I->host_frames = 0;
   }
+  return COX_OK;
+}
+
+int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[7]) {
+  COX_ENTRY();
+  if (!I || !out) return COX_ERR_INVALID_ARG;
+  if (I->method != COX_METHOD_FAST || I->proj) return COX_ERR_UNSUPPORTED;
+  COX_HIP(hipSetDevice(I->layer->device));
+  COX_TRY(sync_all(I));
+  u32 h[8] = {};
+  COX_HIP(hipMemcpy(h, I->fast.d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; ++k) out[k] = h[k];
+  out[4] = I->fast.frames;
+  out[5] = h[4];
+  out[6] = h[5];
   return COX_OK;
 }
 

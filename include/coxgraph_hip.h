@@ -176,10 +176,21 @@ int cox_integrate_points_ex(cox_integrator_t* integ, const float T_G_C[7], const
  *      (e.g. PyTorch's, for tensors allocated on that stream) may recycle the buffers as soon as the caller drops them.
  * Readers of the layer (cox_reg_*, cox_regpoints_from_layer, downloads, clones) wait for the frames in flight by themselves. */
 int cox_integrate_points_dev(cox_integrator_t* integ, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace);
+/* TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace_points) as the reference calls it -- with HOST
+ * buffers (coxgraph/include/coxgraph/map_comm/tsdf_recover.h:71-77) -- without waiting for the frame: the buffers are copied to
+ * one of three staging sets on the engine's own input stream (the copy of frame t+1 runs beside the kernels of frame t) and the
+ * frame is enqueued behind the copy.  Pageable buffers are free again when the call returns (they go through a pinned bounce
+ * buffer: one CPU copy); buffers in pinned memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor after pin_memory()) are
+ * copied from directly and must stay unmodified until cox_integrator_wait_inputs or cox_integrator_sync has returned.
+ * Errors of the frame are reported by the next cox_integrator_sync, as for the *_dev entry points. */
+int cox_integrate_points_async(cox_integrator_t* integ, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace);
+/* wait until every host buffer handed to cox_integrate_points_async so far has been copied (not for the frames themselves) */
+int cox_integrator_wait_inputs(cox_integrator_t* integ);
 /* depth image front end (what depth_image_proc/point_cloud_xyzrgb does ahead of the tsdf_server,
  * coxgraph/launch/cvg/tsdf_client0_cvg.launch:24-30): p_C = d*((u-cx)/fx,(v-cy)/fy,1), row-major
  * point order, non-finite or <=0 depths dropped.  depth_dev: w*h floats in metres on the GPU;
- * rgba_dev: w*h*4 bytes or NULL.  K = {fx, fy, cx, cy}.  Asynchronous. */
+ * rgba_dev: w*h*4 bytes or NULL.  K = {fx, fy, cx, cy}.  Asynchronous: the point count never visits the host (the frame's first
+ * kernel reads it from device memory), so frames stay in flight exactly as with cox_integrate_points_dev. */
 int cox_integrate_depth_dev(cox_integrator_t* integ, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h,
                             const float K[4]);
 /* hip_stream: the hipStream_t (as void*) the caller produces *_dev inputs on; NULL = the legacy default stream.
@@ -218,10 +229,17 @@ typedef enum cox_kernel_class {
   COX_KC_RECORD_SORT = 5, /* radix sort of the (voxel, ray) records */
   COX_KC_FAST_START = 6,  /* fast: start-set sort + flags + ray list */
   COX_KC_FAST_VISITS = 7, /* fast: candidate visits + their sort + inverse */
-  COX_KC_FAST_SWEEPS = 8, /* fast: the Jacobi sweeps of one round */
-  COX_KERNEL_CLASSES = 9
+  COX_KC_FAST_SWEEPS = 8, /* fast: the relaxation launches of round 0 (capped candidate lists) */
+  COX_KC_FAST_ROUND1 = 9, /* fast: round 1 (whole walks for the rays that got through their capped lists: lists, sort, relaxation) */
+  COX_KERNEL_CLASSES = 10
 } cox_kernel_class;
 int cox_integrator_class_times(cox_integrator_t* integ, double ms[COX_KERNEL_CLASSES], uint64_t regions[COX_KERNEL_CLASSES], int reset);
+/* method "fast" only (COX_ERR_UNSUPPORTED otherwise): run totals of the observed-set relaxation since the integrator was created --
+ * out[0] frames the relaxation did not settle and that were redone by the sequential kernel (exact either way), out[1] frames that
+ * needed a second round (some ray got through its capped candidate list), out[2] / out[3] passes of the relaxation in round 0 /
+ * round 1, out[4] frames, out[5] the part of out[0] in which a ray outgrew its round-1 list, out[6] the part in which a grid
+ * barrier gave up.  No reference counterpart (measurement only).  Waits for the frames in flight. */
+int cox_integrator_fast_stats(cox_integrator_t* integ, uint64_t out[7]);
 
 /* self-test: the merged integrator evaluates its sequential mean with an IEEE division whose divisor-only part is
  * hoisted out of the dependent chain; this compares it bit for bit with the compiler's '/' on n pseudo-random operand

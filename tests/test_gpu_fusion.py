@@ -582,3 +582,106 @@ def test_independent_handles_from_several_host_threads(hip):
     assert not errors, errors
     for (ia, va), (ib, vb) in zip(alone, together):
         assert np.array_equal(ia, ib) and np.array_equal(va, vb)
+
+
+# ---- round 3: fast without host round trips, host buffers without waiting, depth frames without a host sync -----------------
+@pytest.mark.parametrize("env", [{}, {"COX_FAST_SEQUENTIAL": "1"}, {"COX_FAST_CAP": "8,8"}, {"COX_FAST_CAP": "16,32"}, {"COX_FAST_CAP": "32,32"}, {"COX_FAST_STREAMS": "1"},
+                                 {"COX_SUBMIT_THREAD": "0"}])
+def test_fast_relaxation_on_the_device_and_its_sequential_fallback(hip, oracle, monkeypatch, env):
+    """`fast` decides convergence, list growth and overflow on the device (one persistent relaxation launch per round, no host round
+    trip), and a frame the two rounds do not finish is redone by ONE lane running the reference's loop (k_fast_sequential;
+    COX_FAST_SEQUENTIAL=1 sends every frame there).  Either way the layer is the oracle's, bit for bit."""
+    import torch
+    sub = 3
+    frames = [synth.make_frame(t) for t in (0, 1, 2, 3, 40, 41)]
+    cfg_kw = dict(integrator_threads=1, **synth.integrator_overrides(0.05))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    a = Layer(hip, 0.05, capacity_blocks=8192)
+    ia = Integrator(hip, a, hip.default_config(**cfg_kw), "fast")
+    for k in env:
+        monkeypatch.delenv(k)
+    b = Layer(oracle, 0.05, capacity_blocks=8192)
+    ib = Integrator(oracle, b, oracle.default_config(**cfg_kw), "fast")
+    dev = [(T, torch.from_numpy(np.ascontiguousarray(p[::sub])).cuda(), torch.from_numpy(np.ascontiguousarray(c[::sub])).cuda()) for T, p, c, _ in frames]
+    torch.cuda.synchronize()
+    for T, xyz, rgba in dev:  # enqueued back to back: the three chains of consecutive frames overlap
+        ia.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), xyz.shape[0])
+    ia.sync()
+    for T, p, c, _ in frames:
+        ib.integrate_points(T, p[::sub], c[::sub])
+    st = ia.fast_stats()
+    print(env, st)
+    assert st["frames"] == len(frames)
+    assert st["sequential_frames_barrier_gave_up"] == 0, st
+    if not env:
+        assert st["round1_frames"] >= 1, st       # some ray gets through its 8 candidate steps in most frames of this scene
+        assert st["sequential_frames"] <= 2, st   # (a ray that outgrows its round-1 list sends its frame to the sequential kernel: rare)
+    if env.get("COX_FAST_SEQUENTIAL"):
+        assert st["sequential_frames"] == len(frames), st
+    compare_stats([ia.last_stats()], [ib.last_stats()])
+    rep = compare_layers(a, b)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+@pytest.mark.parametrize("method", ["merged", "fast", "simple"])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_async_host_entry_equals_the_synchronous_one(hip, method, pinned):
+    """cox_integrate_points_async: host buffers, frames not waited for (H2D of frame t+1 beside the kernels of frame t, three staging
+    sets reused many times), from pageable memory (bounce buffer) and from pinned memory (copied from directly)."""
+    import torch
+    sub = 2 if method != "simple" else 13
+    n_frames = 30
+    frames = [synth.make_frame(t) for t in range(n_frames)]
+    cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
+    a, b = Layer(hip, 0.05, capacity_blocks=16384), Layer(hip, 0.05, capacity_blocks=16384)
+    ia, ib = Integrator(hip, a, cfg, method), Integrator(hip, b, cfg, method)
+    host = []
+    for T, p, c, _ in frames:
+        xyz, rgba = torch.from_numpy(np.ascontiguousarray(p[::sub])), torch.from_numpy(np.ascontiguousarray(c[::sub]))
+        if pinned:
+            xyz, rgba = xyz.pin_memory(), rgba.pin_memory()
+        host.append((T, xyz, rgba))
+    for T, xyz, rgba in host:
+        ia.integrate_points_async(T, xyz.data_ptr(), rgba.data_ptr(), xyz.shape[0])
+    ia.wait_inputs()
+    ia.sync()
+    for T, p, c, _ in frames:
+        ib.integrate_points(T, p[::sub], c[::sub])
+    assert ia.last_stats() == ib.last_stats()
+    ja, va = a.download()
+    jb, vb = b.download()
+    assert np.array_equal(ja, jb) and np.array_equal(va, vb)
+
+
+@pytest.mark.parametrize("method", ["merged", "fast", "simple"])
+def test_depth_stream_without_host_sync(hip, method):
+    """Depth frames enqueued back to back: the point count of every frame stays on the device (the mixed visiting order is
+    computed from it there).  Frames with 2 % invalid pixels, one frame without a single valid pixel in the middle of the stream;
+    against the point path fed with the same points one frame at a time."""
+    import torch
+    n_frames = 12
+    K = synth.INTRINSICS[(640, 480)]
+    frames = [synth.make_frame(t, nan_fraction=0.02) for t in range(n_frames)]
+    cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
+    a, b = Layer(hip, 0.05, capacity_blocks=16384), Layer(hip, 0.05, capacity_blocks=16384)
+    ia, ib = Integrator(hip, a, cfg, method), Integrator(hip, b, cfg, method)
+    colors = torch.from_numpy(synth.frame_colors()).cuda()
+    depths = [torch.from_numpy(d).cuda() for _, _, _, d in frames]
+    empty = torch.zeros((480, 640), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for t, ((T, _, _, _), d) in enumerate(zip(frames, depths)):
+        ia.integrate_depth_dev(T, d.data_ptr(), colors.data_ptr(), 640, 480, K)
+        if t == 5:
+            ia.integrate_depth_dev(T, empty.data_ptr(), colors.data_ptr(), 640, 480, K)
+    ia.sync()
+    assert ia.last_stats()["n_points"] == frames[-1][1].shape[0]  # fetched from the device
+    for t, (T, p, c, _) in enumerate(frames):
+        ib.integrate_points(T, p, c)
+        if t == 5:  # (an empty cloud still resets the fast integrator's sets)
+            ib.integrate_points(T, np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8))
+    sa, sb = ia.last_stats(), ib.last_stats()
+    assert sa == sb, (sa, sb)
+    ja, va = a.download()
+    jb, vb = b.download()
+    assert np.array_equal(ja, jb) and np.array_equal(va, vb)
