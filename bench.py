@@ -7,9 +7,16 @@ submap registrations/s, one coxgraph client per GPU.
 A "step" is one pass of the hot path over one synthetic depth frame: integratePointCloud(T_G_C, points_C, colors) of
 307 200 points into the client's submap layer, inputs already resident in HBM.  The reference configures two integrators on
 this path: `merged` (coxgraph_sim/launch/experiments/mav_3dplanning_2d3dhouse_two.launch:10) and `fast`
-(coxgraph/config/tsdf_server_euroc.yaml:6).  `value` is `merged` (as in round 1); `fast` is a first-class block of its own
-under `other_methods` (own roofline, same frames), and each method's GPU / CPU ratio is taken against the CPU restatement of
-THE SAME method at the reference's 8 integrator threads (`cpu_baseline` = fast, `cpu_baseline.same_method` = merged).
+(coxgraph/config/tsdf_server_euroc.yaml:6).  `value` is `merged` (as in rounds 1 and 2); `fast` is a first-class block of its
+own under `other_methods` (own roofline, same frames) and both are repeated side by side under `headline`; each method's
+GPU / CPU ratio is taken against the CPU restatement of THE SAME method at the reference's 8 integrator threads
+(`cpu_baseline` = fast, `cpu_baseline.same_method` = merged).
+
+The timed stream carries NO instrumentation: kernel-class times come from two passes of their own over the same frames (HIP
+events around the classes inside a stream that keeps frames in flight, and one frame in flight).  `other_configs` holds short,
+bounded runs of the other two shapes BASELINE.json names -- configs[3] (1280x720, 2 cm) and configs[4]'s 1 cm voxels -- each
+with a roofline of its own, so that the fine-voxel numbers are driver-run too.  `registration` registers the two halves of the
+stream that was run (50 % overlap: SURVEY.md section 8d's frames 0-149 / 75-224 at the default 300 steps).
 
 For N > 1 the driver launches one rank per GPU (torch.distributed over RCCL); clients are independent (weak scaling, no
 data-path collective -- SURVEY.md section 8e).  After the fusion timing the ranks run the server's inter-robot leg
@@ -53,9 +60,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)  # the 300-frame 30 Hz stream of SURVEY.md section 8d
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--method", default="merged", choices=["merged", "fast", "simple"])
-    ap.add_argument("--no-events", action="store_true", help="no HIP-event kernel timing inside the timed region")
+    ap.add_argument("--no-events", action="store_true", help="skip the instrumented pass (HIP-event kernel-class timing with frames in flight); the timed stream itself never carries events")
     ap.add_argument("--other-frames", type=int, default=300, help="frames of the same stream also run through the other method (0 = skip)")
     ap.add_argument("--voxel", type=float, default=0.05)
+    ap.add_argument("--width", type=int, default=640, help="depth image width (640 or 1280: the two intrinsics of coxgraph_amd/synth.py)")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--other-config-frames", type=int, default=24, help="timed frames of each `other_configs` block (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the CPU baseline sample (0 = skip); ~10 s of CPU work at the default")
     ap.add_argument("--reg-iters", type=int, default=50)
     ap.add_argument("--pcie-frames", type=int, default=100, help="frames of the PCIe-inclusive legs (0 = skip)")
@@ -106,7 +116,9 @@ def cpu_baseline(frames, voxel, n_frames, threads):
 def pmc_traffic(method):
     """Whole-frame HBM traffic from the committed PMC passes of the same command (rocprofv3 cannot run inside this
     process): sum over the kernels of (FETCH_SIZE + WRITE_SIZE per launch) x (launches per frame)."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{method}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{method}.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{method}.json")
     try:
         pm = json.load(open(path))
         return float(pm["bytes_per_frame"]), {"source": os.path.relpath(path, ROOT), "commit": pm.get("commit"), "frames": pm.get("frames"),
@@ -152,47 +164,58 @@ def main():
     eng = coxgraph_amd.load_engine()
 
     # ---- synthetic stream of this rank's client, resident in HBM before anything is timed ----------
+    W, H = args.width, args.height
+    if (W, H) not in synth.INTRINSICS:
+        raise SystemExit(f"bench.py: no intrinsics for {W}x{H} (have {sorted(synth.INTRINSICS)})")
     n_frames = args.warmup + args.steps
-    host_frames, dev_frames = [], []
     keep_host = max(args.cpu_frames, args.pcie_frames, 1)
-    for t in range(n_frames):
-        # one client per GPU; with several clients they stand 30 degrees apart on the camera circle, so that neighbouring
-        # clients' submaps overlap and the inter-robot constraints have correspondences
-        T, pts, rgba, depth = synth.make_frame(t, client=rank, n_clients=(12 if world > 1 else 1))
-        if t < keep_host:
-            host_frames.append((T, pts, rgba, depth))
-        dev_frames.append((T, torch.from_numpy(pts).cuda(), torch.from_numpy(rgba).cuda(), pts.shape[0]))
-    torch.cuda.synchronize()
-    cfg = eng.default_config(**synth.integrator_overrides(args.voxel))
 
-    def clock_ramp(method, seconds=0.3):
+    def make_frames(n, w, h, keep):
+        """-> (host frames (the first `keep`), device-resident frames)"""
+        host, dev = [], []
+        for t in range(n):
+            # one client per GPU; with several clients they stand 30 degrees apart on the camera circle, so that neighbouring
+            # clients' submaps overlap and the inter-robot constraints have correspondences
+            T, pts, rgba, depth = synth.make_frame(t, client=rank, n_clients=(12 if world > 1 else 1), w=w, h=h)
+            if t < keep:
+                host.append((T, pts, rgba, depth))
+            dev.append((T, torch.from_numpy(pts).cuda(), torch.from_numpy(rgba).cuda(), pts.shape[0]))
+        torch.cuda.synchronize()
+        return host, dev
+
+    host_frames, dev_frames = make_frames(n_frames, W, H, keep_host)
+
+    def config_for(voxel):
+        return eng.default_config(**synth.integrator_overrides(voxel))
+    cfg = config_for(args.voxel)
+
+    def clock_ramp(method, dev, cfg_, voxel, seconds=0.3):
         """Untimed extra frames on a scratch layer so that the timed region starts at running clocks (the reported `warmup`
         frames still go through the measured layer)."""
         if args.no_ramp:
             return
-        scratch = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        si = Integrator(eng, scratch, cfg, method)
+        scratch = Layer(eng, voxel, device=local_rank, capacity_blocks=32768)
+        si = Integrator(eng, scratch, cfg_, method)
         t0 = time.perf_counter()
         i = 0
         while time.perf_counter() - t0 < seconds:
-            T, xyz, rgba, n = dev_frames[i % n_frames]
+            T, xyz, rgba, n = dev[i % len(dev)]
             si.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
             i += 1
             if i % 16 == 0:
                 si.sync()
         si.sync()
 
-    def run_stream(method, steps, timed_events):
-        """warm-up + `steps` timed frames on a fresh layer; barrier + device sync on both sides, MAX over ranks."""
-        layer = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        integ = Integrator(eng, layer, cfg, method)
-        if timed_events:
-            # timed events are not free (a timestamped marker serialises its stream: 7 % of the throughput at every 4th frame):
-            # every 2nd frame of a short run (10 samples at --steps 20), every 8th otherwise (37 samples at the default 300)
-            integ.set_profiling(2 if steps < 64 else 8)
-        clock_ramp(method)
-        for i in range(args.warmup):
-            T, xyz, rgba, n = dev_frames[i]
+    def run_stream(method, steps, warmup, dev, cfg_, voxel, events=0):
+        """warm-up + `steps` timed frames on a fresh layer; barrier + device sync on both sides, MAX over ranks.  events = n > 0:
+        HIP-event markers around the kernel classes of every n-th frame (a pass of its own: never the run `value` comes from)."""
+        layer = Layer(eng, voxel, device=local_rank, capacity_blocks=32768)
+        integ = Integrator(eng, layer, cfg_, method)
+        if events:
+            integ.set_profiling(events)
+        clock_ramp(method, dev, cfg_, voxel)
+        for i in range(warmup):
+            T, xyz, rgba, n = dev[i]
             integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
         integ.sync()
         integ.class_times(reset=True)
@@ -201,8 +224,8 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + steps):
-            T, xyz, rgba, n = dev_frames[i]
+        for i in range(warmup, warmup + steps):
+            T, xyz, rgba, n = dev[i]
             integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
             if args.serial:
                 integ.sync()
@@ -215,35 +238,35 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        live = integ.class_times() if timed_events else None
+        live = integ.class_times() if events else None
         hms, hn = integ.host_time()
-        run_stream.host_ms_per_frame = hms / max(hn, 1)   # caller's thread inside the integrate calls (launch-rate bound at 5 cm)
+        run_stream.host_ms_per_frame = hms / max(hn, 1)   # caller's thread inside the integrate calls
         return layer, integ, dt, live
 
-    def roofline_of(method, steps, live):
+    def roofline_of(method, steps, warmup, dev, cfg_, voxel, live, live_every):
         """Algorithmic bytes need per-frame counters, which only a synchronous pass can read: the same frames once more, one in
         flight, on a fresh layer; that pass also gives the kernel classes' undisturbed durations."""
         stats_sum = dict(n_valid=0, n_touched_voxels=0, n_updates=0, n_rays=0)
         stats_max = dict(max_bundle_points=0, max_voxel_updates=0)
-        layer2 = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        integ2 = Integrator(eng, layer2, cfg, method)
+        layer2 = Layer(eng, voxel, device=local_rank, capacity_blocks=32768)
+        integ2 = Integrator(eng, layer2, cfg_, method)
         integ2.set_profiling(True)
-        for i in range(args.warmup + steps):
-            T, xyz, rgba, n = dev_frames[i]
+        for i in range(warmup + steps):
+            T, xyz, rgba, n = dev[i]
             integ2.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
             integ2.sync()
-            if i >= args.warmup:
+            if i >= warmup:
                 st = integ2.last_stats()
                 for k in stats_sum:
                     stats_sum[k] += st[k]
                 for k in stats_max:
                     stats_max[k] = max(stats_max[k], st[k])
-            elif i == args.warmup - 1:
+            elif i == warmup - 1:
                 integ2.class_times(reset=True)
         serial = integ2.class_times()
+        fast_stats = integ2.fast_stats() if method == "fast" else None
         st = live if live is not None else serial
-        per_frame = lambda d: {k: (v[0] / v[1] if v[1] else None) for k, v in d.items() if v[1]}
-        # a class may have several regions per frame (the fast integrator's rounds): price it per FRAME
+        # a class may have several regions per frame: price it per FRAME
         frames_timed = max(st["apply"][1], 1)
         per_frame_ms = {k: v[0] / frames_timed for k, v in st.items() if v[1]}
         # SURVEY.md section 8d: B_frame = 16 B per valid point + 24 B per touched voxel (12-B TsdfVoxel read + written)
@@ -251,42 +274,52 @@ def main():
         dom = max(per_frame_ms, key=per_frame_ms.get)
         ms = per_frame_ms[dom]
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        traffic, src = pmc_traffic(method)
+        traffic, src = pmc_traffic(method) if (abs(voxel - 0.05) < 1e-9 and len(dev) and dev[0][3] <= 640 * 480) else (None, {"source": None, "note": "PMC passes are collected for the headline configuration only"})
         roof = {"bound": "hbm", "kernel": KERNELS_OF_CLASS[dom], "kernel_class": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_ratio": (traffic / alg_bytes) if traffic else None,
                 "traffic_scope": "whole frame: sum over all kernels of (FETCH_SIZE + WRITE_SIZE) per launch x launches per frame", "traffic_source": src,
                 "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": frames_timed,
                 "launch_unit": "one frame's launches of this kernel class (HIP events around the class on its own stream)",
-                "timing": ("HIP events inside the timed region, every 2nd frame" if steps < 64 else "HIP events inside the timed region, every 8th frame") if live is not None
-                          else "HIP events, one frame in flight",
+                "timing": (f"HIP events around the classes of every {live_every}. frame in a pass of its own with frames in flight (the timed stream carries none)"
+                           if live is not None else "HIP events, one frame in flight"),
                 "class_ms_per_frame": per_frame_ms, "class_ms_per_frame_one_in_flight": {k: v[0] / max(serial["apply"][1], 1) for k, v in serial.items() if v[1]},
                 "whole_frame_algorithmic_GBps": None,
                 "note": "the path is bound by dependent in-order chains and launch latency, not by HBM, at 5 cm (DESIGN.md section 6)"}
         fstats = {k: v / max(steps, 1) for k, v in stats_sum.items()}
-        return roof, fstats, stats_max, alg_bytes
+        return roof, fstats, stats_max, alg_bytes, fast_stats
+
+    def measure(method, steps, warmup, dev, cfg_, voxel, profile=True, events=True):
+        """clean timed run (no instrumentation) -> frames/s; then, unless disabled, the instrumented pass and the one-in-flight pass"""
+        layer, integ, dt, _ = run_stream(method, steps, warmup, dev, cfg_, voxel, events=0)
+        host_ms = run_stream.host_ms_per_frame
+        out = {"value": world * steps / dt, "unit": "frames/s", "frames": steps, "ms_per_step": dt / steps * 1e3, "host_submit_ms_per_frame": host_ms}
+        if profile and rank == 0:
+            live, every = None, 0
+            if events:
+                every = 2 if steps < 64 else 8
+                _, _, _, live = run_stream(method, steps, warmup, dev, cfg_, voxel, events=every)
+            roof, fstats, crit, ab, fst = roofline_of(method, steps, warmup, dev, cfg_, voxel, live, every)
+            roof["whole_frame_algorithmic_GBps"] = ab / (dt / steps) / 1e9
+            out.update({"roofline": roof, "frame_stats_mean": fstats, "critical_path": crit})
+            if fst:
+                out["relaxation"] = fst
+        return layer, integ, dt, out
 
     # ---- headline ----------------------------------------------------------------------------------------------------
-    layer, integ, dt, live = run_stream(args.method, args.steps, not args.no_events)
-    fps = world * args.steps / dt
-    host_ms = run_stream.host_ms_per_frame
-    roofline, frame_stats, crit, alg_bytes = (None, None, None, None)
-    if rank == 0 and not args.no_profile_pass:
-        roofline, frame_stats, crit, alg_bytes = roofline_of(args.method, args.steps, live)
-        roofline["whole_frame_algorithmic_GBps"] = alg_bytes / (dt / args.steps) / 1e9
+    layer, integ, dt, head = measure(args.method, args.steps, args.warmup, dev_frames, cfg, args.voxel, profile=not args.no_profile_pass, events=not args.no_events)
+    fps = head["value"]
+    host_ms = head["host_submit_ms_per_frame"]
+    roofline, frame_stats, crit = head.get("roofline"), head.get("frame_stats_mean"), head.get("critical_path")
 
     # ---- the other method on the same stream, as a block of its own -------------------------------------------------------
     other = None
     if rank == 0 and world == 1 and args.other_frames > 0 and args.method in ("fast", "merged"):
         om = "merged" if args.method == "fast" else "fast"
         nf = min(args.other_frames, args.steps)
-        _, _, dto, liveo = run_stream(om, nf, not args.no_events)
-        ro, fso, co, ab = (None, None, None, None)
-        if not args.no_profile_pass:
-            ro, fso, co, ab = roofline_of(om, nf, liveo)
-            ro["whole_frame_algorithmic_GBps"] = ab / (dto / nf) / 1e9
-        other = {om: {"value": nf / dto, "unit": "frames/s", "frames": nf, "ms_per_step": dto / nf * 1e3, "roofline": ro, "frame_stats_mean": fso, "critical_path": co,
-                      "note": ("MergedTsdfIntegrator semantics" if om == "merged" else "FastTsdfIntegrator semantics at integrator_threads=1") +
-                              ", bit-exact vs the CPU oracle (DESIGN.md section 5)"}}
+        _, _, _, blk = measure(om, nf, args.warmup, dev_frames, cfg, args.voxel, profile=not args.no_profile_pass, events=not args.no_events)
+        blk["note"] = ("MergedTsdfIntegrator semantics" if om == "merged" else "FastTsdfIntegrator semantics at integrator_threads=1") + \
+                      ", bit-exact vs the CPU oracle (DESIGN.md section 5)"
+        other = {om: blk}
 
         # the fourth integrator the reference configures (method: "projective", tsdf_server_default.yaml:6, tsdf_server_carla.yaml:6):
         # a gather, not a ray caster; same frames through the yaml files' sensor model (1280 x 960 over 360 degrees)
@@ -302,7 +335,6 @@ def main():
                 ip_.integrate_points_dev(T, xyz.data_ptr(), 0, n)
             ip_.sync()
             t0p = time.perf_counter()
-            blocks = 0
             for i in range(args.warmup, args.warmup + nfp):
                 T, xyz, rgba, n = dev_frames[i]
                 ip_.integrate_points_dev(T, xyz.data_ptr(), 0, n)
@@ -314,58 +346,136 @@ def main():
                                    "update_kernel_bytes_last_frame": stp["n_touched_blocks"] * 2 * 49152,
                                    "note": "ProjectiveTsdfIntegrator semantics (range image + per-voxel gather), frames queued on one stream, no colours; bit-exact vs "
                                            "the CPU oracle (tests/test_gpu_projective.py); k_proj_update streams 96 KB per marked block (DESIGN.md section 5d)"}
+            del ip_, lp_
         except Exception as e:  # never let the extra block cost the line
             other["projective"] = {"error": str(e)}
+
+    # ---- the other shapes BASELINE.json names, short and bounded, each with a roofline of its own ---------------------------------
+    other_configs = None
+    if rank == 0 and world == 1 and args.other_config_frames > 0 and abs(args.voxel - 0.05) < 1e-9 and (W, H) == (640, 480):
+        other_configs = {}
+        ocf, ocw = args.other_config_frames, 6
+        for name, (w2, h2, vox2) in (("configs[3]: 1280x720, 2 cm (coxgraph/config/tsdf_server_rs.yaml:12-17)", (1280, 720, 0.02)),
+                                     ("configs[4] voxel size: 640x480, 1 cm (rays to 3 m, extrapolated: the reference has no 1 cm config)", (640, 480, 0.01))):
+            try:
+                if (w2, h2) == (W, H):
+                    dev2 = dev_frames          # the headline's frames (as many of them as the run has)
+                else:
+                    _, dev2 = make_frames(ocw + ocf, w2, h2, 0)
+                nf2 = min(ocf, len(dev2) - ocw)
+                if nf2 < 4:
+                    raise RuntimeError(f"only {len(dev2)} frames available")
+                cfg2 = config_for(vox2)
+                blocks = {}
+                for m2 in ("merged", "fast"):
+                    nfm = nf2 if m2 == "merged" else max(4, nf2 // 2)
+                    _, _, _, blk = measure(m2, nfm, ocw, dev2, cfg2, vox2, profile=(m2 == "merged" and not args.no_profile_pass), events=False)
+                    blocks[m2] = blk
+                other_configs[name] = {"width": w2, "height": h2, "voxel_size_m": vox2, "points_per_frame": w2 * h2, "warmup": ocw, **blocks}
+                if dev2 is not dev_frames:
+                    del dev2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                other_configs[name] = {"error": str(e)}
 
     # ---- PCIe-inclusive: what the boundary costs when the caller hands over host buffers -----------------------------------
     pcie = None
     if rank == 0 and world == 1 and args.pcie_frames > 0:
         nf = min(args.pcie_frames, len(host_frames))
-        lp = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        ip = Integrator(eng, lp, cfg, args.method)
-        for T, p, c, _ in host_frames[:5]:
-            ip.integrate_points(T, p, c)
-        t0 = time.perf_counter()
-        for T, p, c, _ in host_frames[:nf]:
-            ip.integrate_points(T, p, c)  # cox_integrate_points: 4.9 MB H2D + frame + sync, one frame in flight
-        dt_pts = time.perf_counter() - t0
-        # depth images (1.2 MB + 1.2 MB colour) from pinned memory on the caller's own stream, ordered against the engine
-        # (cox_integrator_set_input_stream): the H2D copy of frame t+1 overlaps the kernels of frame t
-        ld = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-        idp = Integrator(eng, ld, cfg, args.method)
-        side = torch.cuda.Stream()
-        idp.set_input_stream(side.cuda_stream)
-        K = np.array(synth.INTRINSICS[(640, 480)], np.float32)
-        rgba_img = torch.from_numpy(synth.frame_colors()).pin_memory()
-        pinned = [torch.from_numpy(d).pin_memory() for _, _, _, d in host_frames[:nf]]
-        with torch.cuda.stream(side):
-            for (T, _, _, _), hd in zip(host_frames[:5], pinned[:5]):  # untimed: first launches of the depth kernels, allocator warm-up
-                idp.integrate_depth_dev(T, hd.to("cuda", non_blocking=True).data_ptr(), rgba_img.to("cuda", non_blocking=True).data_ptr(), 640, 480, K)
+        pcie = {"frames": nf, "bytes_per_frame_points": int(host_frames[0][1].nbytes + host_frames[0][2].nbytes),
+                "bytes_per_frame_depth": int(host_frames[0][3].nbytes + W * H * 4),
+                "note": "never `value`.  host points: cox_integrate_points_async (the reference's boundary, tsdf_recover.h:71-77: host buffers; H2D on the engine's "
+                        "input stream beside the kernels of earlier frames) from pinned and from pageable memory (pageable: one CPU copy into a pinned bounce buffer), "
+                        "and the synchronous cox_integrate_points; depth: pinned depth + colour images copied on the caller's stream, cox_integrate_depth_dev (point "
+                        "count stays on the device)"}
+        K = np.array(synth.INTRINSICS[(W, H)], np.float32)
+        for m in (["merged", "fast"] if args.method in ("merged", "fast") else [args.method]):
+            res = {}
+            pinned = [(T, torch.from_numpy(p).pin_memory(), torch.from_numpy(c).pin_memory()) for T, p, c, _ in host_frames[:nf]]
+            for label, src in (("host_points_pinned_frames_per_s", pinned), ("host_points_pageable_frames_per_s", [(T, torch.from_numpy(p), torch.from_numpy(c)) for T, p, c, _ in host_frames[:nf]])):
+                lp = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+                ip = Integrator(eng, lp, cfg, m)
+                for T, x, c in src:  # untimed: every buffer once (a pinned buffer's first DMA pays for its mappings; a sensor driver reuses a ring of them)
+                    ip.integrate_points_async(T, x.data_ptr(), c.data_ptr(), x.shape[0])
+                ip.sync()
+                ip2 = Integrator(eng, Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768), cfg, m)
+                del ip
+                ip = ip2
+                t0 = time.perf_counter()
+                for T, x, c in src:
+                    ip.integrate_points_async(T, x.data_ptr(), c.data_ptr(), x.shape[0])
+                ip.sync()
+                res[label] = nf / (time.perf_counter() - t0)
+                del ip, lp
+            lp = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+            ip = Integrator(eng, lp, cfg, m)
+            nsync = min(nf, 30)
+            for T, p, c, _ in host_frames[:3]:
+                ip.integrate_points(T, p, c)
+            t0 = time.perf_counter()
+            for T, p, c, _ in host_frames[:nsync]:
+                ip.integrate_points(T, p, c)  # cox_integrate_points: H2D + frame + sync, one frame in flight
+            res["host_points_synchronous_frames_per_s"] = nsync / (time.perf_counter() - t0)
+            del ip, lp
+            # depth images (1.2 MB + 1.2 MB colour) from pinned host memory through cox_integrate_depth_async (copied and converted on the
+            # frame's own ray-generation stream; the point count never visits the host) ...
+            rgba_img = torch.from_numpy(synth.frame_colors(W, H)).pin_memory()
+            pinned_d = [torch.from_numpy(d).pin_memory() for _, _, _, d in host_frames[:nf]]
+            ld = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+            idp = Integrator(eng, ld, cfg, m)
+            for (T, _, _, _), hd in zip(host_frames[:nf], pinned_d):  # untimed: every pinned image once
+                idp.integrate_depth_async(T, hd.data_ptr(), rgba_img.data_ptr(), W, H, K)
             idp.sync()
             t0 = time.perf_counter()
-            for (T, _, _, _), hd in zip(host_frames[:nf], pinned):
-                dd = hd.to("cuda", non_blocking=True)
-                cc = rgba_img.to("cuda", non_blocking=True)
-                idp.integrate_depth_dev(T, dd.data_ptr(), cc.data_ptr(), 640, 480, K)
+            for (T, _, _, _), hd in zip(host_frames[:nf], pinned_d):
+                idp.integrate_depth_async(T, hd.data_ptr(), rgba_img.data_ptr(), W, H, K)
             idp.sync()
-            dt_depth = time.perf_counter() - t0
-        pcie = {"method": args.method, "frames": nf,
-                "host_points_frames_per_s": nf / dt_pts, "host_points_bytes_per_frame": int(host_frames[0][1].nbytes + host_frames[0][2].nbytes),
-                "depth_image_frames_per_s": nf / dt_depth, "depth_image_bytes_per_frame": int(host_frames[0][3].nbytes + 640 * 480 * 4),
-                "note": "never `value`: host buffers through cox_integrate_points (synchronous, one frame in flight) and pinned depth + colour images "
-                        "through cox_integrate_depth_dev on the caller's stream"}
-        del ip, lp, idp, ld
+            res["depth_image_frames_per_s"] = nf / (time.perf_counter() - t0)
+            del idp, ld
+            # ... and as device images the caller copies on a stream of its own, ordered against the engine (cox_integrator_set_input_stream)
+            ld = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+            idp = Integrator(eng, ld, cfg, m)
+            side = torch.cuda.Stream()
+            idp.set_input_stream(side.cuda_stream)
+            with torch.cuda.stream(side):
+                for (T, _, _, _), hd in zip(host_frames[:5], pinned_d[:5]):  # untimed: first launches of the depth kernels, allocator warm-up
+                    idp.integrate_depth_dev(T, hd.to("cuda", non_blocking=True).data_ptr(), rgba_img.to("cuda", non_blocking=True).data_ptr(), W, H, K)
+                idp.sync()
+                t0 = time.perf_counter()
+                for (T, _, _, _), hd in zip(host_frames[:nf], pinned_d):
+                    dd = hd.to("cuda", non_blocking=True)
+                    cc = rgba_img.to("cuda", non_blocking=True)
+                    idp.integrate_depth_dev(T, dd.data_ptr(), cc.data_ptr(), W, H, K)
+                idp.sync()
+                res["depth_image_on_caller_stream_frames_per_s"] = nf / (time.perf_counter() - t0)
+            del idp, ld, pinned, pinned_d
+            resident = fps if m == args.method else ((other or {}).get(m, {}).get("value"))
+            if resident:
+                res["resident_frames_per_s"] = resident
+                res["fraction_of_resident"] = {k.replace("_frames_per_s", ""): v / resident for k, v in res.items() if k.endswith("_frames_per_s") and k != "resident_frames_per_s"}
+            pcie[m] = res
 
     # ---- registrations/s: the server's configured constraint (config/server.yaml:28-31): isosurface vertices of the reference
-    # submap against the ESDF of the reading submap, sampling_ratio 0.3 drawn by the weighted sampler on the GPU -------------
+    # submap against the ESDF of the reading submap, sampling_ratio 0.3 drawn by the weighted sampler on the GPU.  The pair is
+    # SURVEY.md section 8d's: two submaps of the stream that was run with 50 % overlap -- frames [0, 2m) and [m, 3m), m = a third
+    # of the frames (0-149 / 75-224 of the full stream's first 225) -- the reading one perturbed by (5 cm, -3 cm, 2 cm, 1 degree) ---
     reg = None
     trunc = cfg.default_truncation_distance
     esdf_cfg = dict(max_distance_m=2.0, min_distance_m=0.5 * trunc)
-    if rank == 0 and args.reg_iters > 0:
+    if rank == 0 and world == 1 and args.reg_iters > 0:  # (N > 1: the inter-robot leg below is the registration measurement)
         from coxgraph_amd.posegraph import PoseGraphInterface
+        m3 = max(1, len(dev_frames) // 3)
+        subs = []
+        for lo, hi in ((0, 2 * m3), (m3, min(3 * m3, len(dev_frames)))):
+            ls = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
+            isub = Integrator(eng, ls, cfg, "merged")
+            for T, xyz, rgba, n in dev_frames[lo:hi]:
+                isub.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
+            isub.sync()
+            subs.append((ls, isub, (lo, hi)))
         t0 = time.perf_counter()
-        ref = RegPoints.from_isosurface(eng, layer, 1.0)
-        esdf = layer.esdf(**esdf_cfg)
+        ref = RegPoints.from_isosurface(eng, subs[0][0], 1.0)   # finishSubmap() of the reference submap ...
+        esdf = subs[1][0].esdf(**esdf_cfg)                       # ... and of the reading one
         finish_ms = (time.perf_counter() - t0) * 1e3
         n_res = int(0.3 * ref.n)
         g = Registration(eng, ref, esdf)
@@ -382,7 +492,7 @@ def main():
                     fn()
                 out.append(per_call * calls / (time.perf_counter() - t1))
             return sorted(out)[len(out) // 2]
-        g.normal_eq(pr, pd)
+        n_corr = g.normal_eq(pr, pd)[3]
         g.kernel_time(reset=True)
         one_at_a_time = rate(lambda: g.normal_eq(pr, pd), args.reg_iters)
         kms, kl = g.kernel_time()
@@ -404,10 +514,14 @@ def main():
         _, second = pg.optimize(enable_registration=True)
         solve_ms = (time.perf_counter() - t2) * 1e3
         reg = {"registrations_per_s": in_flight, "registrations_per_s_one_at_a_time": one_at_a_time, "residuals_per_registration": n_res, "registration_points": int(ref.n),
+               "correspondences": int(n_corr),
+               "pair": f"reference submap = frames {subs[0][2][0]}..{subs[0][2][1] - 1}, reading submap = frames {subs[1][2][0]}..{subs[1][2][1] - 1} of this run's stream (50 % overlap), "
+                       "reading pose off by (0.05, -0.03, 0.02) m and 1 degree",
                "point_set": "isosurface vertices (explicit_to_implicit), ESDF reading", "finish_submap_ms": finish_ms,
                "kernel_ms": kms / max(kl, 1), "kernel_GBps_algorithmic": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9,
                "roofline_frac": n_res * (20 + 8 * 12) / (kms / max(kl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                "two_stage_solve_ms": solve_ms, "solve_evaluations": second["evaluations"], "solved_pose_error": [float(x) for x in pg.getPoseMap()[1]]}
+        del subs
 
     # ---- N > 1: submap exchange + inter-robot registration ------------------------------------------------------------------
     dist_reg = None
@@ -509,16 +623,19 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: 1 client per GPU, 640x480 synthetic depth stream, {args.voxel * 100:.0f} cm voxels, "
+            "config": {"workload": f"configs[1]: 1 client per GPU, {W}x{H} synthetic depth stream, {args.voxel * 100:.0f} cm voxels, "
                                    f"{args.method} integrator semantics (the reference's configured method is fast; bit-exact vs CPU oracle), points resident in HBM",
-                       "points_per_frame": 307200, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
+                       "points_per_frame": W * H, "method": args.method, "voxel_size_m": args.voxel, "clients": world},
+            # both integrators the reference configures on this path, side by side (value = the `--method` one)
+            "headline": {args.method: fps, **({k: v.get("value") for k, v in (other or {}).items() if k in ("merged", "fast")})},
+            "relaxation": head.get("relaxation"),
             "frame_stats_mean": frame_stats,
             "host_submit_ms_per_frame": host_ms,   # caller's thread inside cox_integrate_points_dev (the other half of a frame is enqueued by the integrator's submission thread)
             "critical_path": dict(crit, note="longest sequential chains of any timed frame: points of the largest bundle (merged), updates of the busiest voxel") if crit else None,
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": ({"merged": (fps if args.method == "merged" else (other or {}).get("merged", {}).get("value", 0.0)) / cpu["same_method"]["value"],
                               "fast": (fps if args.method == "fast" else (other or {}).get("fast", {}).get("value", 0.0)) / cpu["value"]} if cpu else None),
-            "other_methods": other, "pcie_inclusive": pcie, "registration": reg, "distributed_registration": dist_reg,
+            "other_methods": other, "other_configs": other_configs, "pcie_inclusive": pcie, "registration": reg, "distributed_registration": dist_reg,
         }
         print(json.dumps(line))
     if world > 1:

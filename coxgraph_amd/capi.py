@@ -273,6 +273,13 @@ class Integrator:
         self.eng.check(self.eng.fn("integrate_depth_dev")(self.h, _fp(T), C.c_void_p(depth_ptr), C.c_void_p(rgba_ptr or 0),
                                                           C.c_int(w), C.c_int(h), _fp(K)), "integrate_depth_dev")
 
+    def integrate_depth_async(self, T_G_C, depth_ptr, rgba_ptr, w, h, K):
+        """Host depth / colour images (addresses), frame not waited for."""
+        T = np.ascontiguousarray(T_G_C, np.float32)
+        K = np.ascontiguousarray(K, np.float32)
+        self.eng.check(self.eng.fn("integrate_depth_async")(self.h, _fp(T), C.c_void_p(depth_ptr), C.c_void_p(rgba_ptr or 0),
+                                                            C.c_int(w), C.c_int(h), _fp(K)), "integrate_depth_async")
+
     def set_input_stream(self, stream_ptr, enable=True):
         """Order *_dev calls against the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
         self.eng.check(self.eng.fn("integrator_set_input_stream")(self.h, C.c_void_p(stream_ptr or 0), C.c_int(int(enable))), "integrator_set_input_stream")
@@ -306,10 +313,10 @@ class Integrator:
 
     def fast_stats(self):
         """method 'fast': run totals of the observed-set relaxation (cox_integrator_fast_stats)."""
-        out = (C.c_uint64 * 7)()
+        out = (C.c_uint64 * 8)()
         self.eng.check(self.eng.fn("integrator_fast_stats")(self.h, out), "integrator_fast_stats")
-        return dict(sequential_frames=int(out[0]), round1_frames=int(out[1]), passes_round0=int(out[2]), passes_round1=int(out[3]),
-                    frames=int(out[4]), sequential_frames_list_outgrown=int(out[5]), sequential_frames_barrier_gave_up=int(out[6]))
+        return dict(sequential_frames=int(out[0]), round1_frames=int(out[1]), passes_round0=int(out[2]), passes_later_rounds=int(out[3]),
+                    frames=int(out[4]), sequential_frames_list_outgrown=int(out[5]), sequential_frames_barrier_gave_up=int(out[6]), frames_with_three_rounds_or_more=int(out[7]))
 
     def host_time(self, reset=False):
         """(ms, frames): host time spent inside the integrate calls (enqueueing; cox_integrator_host_time)."""

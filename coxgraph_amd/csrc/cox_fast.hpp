@@ -139,12 +139,12 @@ __global__ void __launch_bounds__(256) k_fast_rays(const FrameParams* __restrict
 template <u32 kAxisCap>
 __global__ void __launch_bounds__(256) k_fast_visits(const FrameParams* __restrict__ Pp, FastFrame FF, RayArrays R, u64* __restrict__ vhash, u32* __restrict__ vkey,
                                                      u32* __restrict__ vval, u32* __restrict__ vray, u32* __restrict__ voff, const u32* __restrict__ cap, u32 stride,
-                                                     u32 vcap, Counters* cnt) {
+                                                     int round, Counters* cnt) {
   const FrameParams P = *Pp;
   __shared__ float lds_t[4][3 * kAxisCap];
   __shared__ u32 lds_path[4][3 * kAxisCap];
   if (uniform_u32(cnt->fast.overflow) != 0u) return;  // lists that do not fit: the sequential kernel takes the frame
-  if (stride == 0 && uniform_u32(cnt->fast.grew) == 0u) return;
+  if (round > 0 && uniform_u32(cnt->fast.grew[round]) == 0u) return;
   const u32 n_rays = uniform_u32(cnt->n_rays);
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
@@ -324,9 +324,9 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
                                                                   const u32* __restrict__ long_list, const u32* __restrict__ d_n_rays, int fences) {
   __shared__ u32 lds_ok;
   FastBarrier* bar = &ctl->bar[round];
-  if (ctl->overflow || (round == 1 && (ctl->grew == 0u || ctl->settled[0] == 0u))) return;  // (uniform over the grid: nobody waits for anybody)
+  if (ctl->overflow || (round > 0 && ctl->grew[round] == 0u)) return;  // (uniform over the grid: nobody waits for anybody)
   const u32 n_rays = *d_n_rays;
-  const u32 n_long = round == 1 ? ctl->n_long : 0u;
+  const u32 n_long = round > 0 ? ctl->n_long : 0u;
   const u32 lane = lane_id();
   const u32 n_waves = (gridDim.x * blockDim.x) >> 6;
   const u32 wave0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -380,9 +380,10 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
       const u32 r = uniform_u32(long_list[q]);
       const u32 ns = uniform_u32(list_len[r]), off = uniform_u32(V.voff[r]);
       u32 carry = 0, stop = ns;
-      // most rays stop within their first few steps and every tested step costs half a dozen gathers, so the walk is tested in
-      // growing segments: 16 steps, the rest of the first 64, then 256 at a time (four independent gathers per lane in flight)
-      u32 base = 0, seg = 16;
+      // every tested step costs half a dozen gathers, so a ray that stopped early last time is tested in growing segments: 16 steps,
+      // the rest of the first 64, then 256 at a time (four independent gathers per lane in flight); one that went far (most of the
+      // rays that have their whole walk) starts with 256: one batch of dependent round trips instead of three
+      u32 base = 0, seg = (fast_ld(&reach[r]) >= 48u) ? 256u : 16u;
       while (base < ns && stop == ns) {
         const u32 len = uniform_u32(min(seg, ns - base));
         bool coll[4];
@@ -438,31 +439,33 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
 // capped list, once in a few frames.  So every other ray's list grows as well in round 1, to cap1 steps (a few times the cap of
 // round 0): room for such second-order moves.  A ray that still ends up at the end of a list shorter than its walk sends the
 // frame to k_fast_sequential.
-__global__ void __launch_bounds__(256) k_fast_grow(const u32* __restrict__ nfull, u32* __restrict__ cap, u32* reach, FastCtl* ctl, u32 cap1,
+__global__ void __launch_bounds__(256) k_fast_grow(const u32* __restrict__ nfull, u32* __restrict__ cap, u32* reach, FastCtl* ctl, int round, u32 cap1,
                                                    u32* __restrict__ long_list, const u32* __restrict__ d_n_rays) {
   const u32 n_rays = *d_n_rays;
-  if (ctl->overflow || ctl->settled[0] == 0u || ctl->want_more[0] == 0u) return;  // round 0 did not settle (k_fast_sequential takes over) / nobody wants more
+  const int prev = round - 1;
+  // the round before did not run or did not settle (k_fast_sequential takes over) / nobody wants more
+  if (ctl->overflow || (prev > 0 && ctl->grew[prev] == 0u) || ctl->settled[prev] == 0u || ctl->want_more[prev] == 0u) return;
   bool any = false;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
     const u32 c = cap[r], nf = nfull[r];
     if (c < nf && reach[r] >= c) {
       cap[r] = nf;    // a ray that got through its first steps unstopped mostly goes all the way: take the whole walk
       reach[r] = nf;  // guess: it keeps going
-      if (nf > cap1) long_list[atomicAdd(&ctl->n_long, 1u)] = r;  // (one wave each in round 1; their order does not matter)
+      if (nf > cap1) long_list[atomicAdd(&ctl->n_long, 1u)] = r;  // (one wave each from now on; their order does not matter)
       any = true;
     } else if (c < nf) {
-      cap[r] = min(nf, cap1);  // (its reach stays: the guess of round 0's fixed point)
+      cap[r] = min(nf, cap1);  // (its reach stays: the guess of the previous round's fixed point)
     }
   }
   if (__ballot(any) && lane_id() == 0) {
-    if (__hip_atomic_load(&ctl->grew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&ctl->grew, 1u);
-    ctl->scan_n = n_rays;  // (every writer stores the same value)
+    if (__hip_atomic_load(&ctl->grew[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&ctl->grew[round], 1u);
+    ctl->scan_n[round] = n_rays;  // (every writer stores the same value)
   }
 }
 // round 1: offsets of the grown lists (exclusive scan of cap over the rays, one workgroup; nothing to do without growth)
-__global__ void __launch_bounds__(1024) k_fast_scan_caps(const u32* __restrict__ cap, u32* __restrict__ voff, FastCtl* ctl, u32 n_max, u32 vcap) {
+__global__ void __launch_bounds__(1024) k_fast_scan_caps(const u32* __restrict__ cap, u32* __restrict__ voff, FastCtl* ctl, int round, u32 n_max, u32 vcap) {
   __shared__ u32 lds[16];
-  const u32 n = min(ctl->scan_n, n_max);
+  const u32 n = min(ctl->scan_n[round], n_max);
   if (n == 0) return;
   u32 carry = 0;
   for (u32 base = 0; base < n; base += 1024 * 4) {
@@ -483,25 +486,32 @@ __global__ void __launch_bounds__(1024) k_fast_scan_caps(const u32* __restrict__
     carry += total;  // (sums beyond 2^32 cannot occur: the lists' total is bounded by the record capacity, < 2^31)
   }
   if (threadIdx.x == 0) {
-    ctl->n_visits[1] = carry > vcap ? 0u : carry;
+    ctl->n_visits[round] = carry > vcap ? 0u : carry;
     if (carry > vcap) ctl->overflow = 1u;
   }
 }
 // the same bookkeeping behind the three-launch scan (many rays: fine voxels)
-__global__ void k_fast_scan_caps_done(FastCtl* ctl, u32 vcap) {
-  if (ctl->scan_n == 0u) ctl->n_visits[1] = 0u;
-  if (ctl->n_visits[1] > vcap) {
-    ctl->n_visits[1] = 0u;
+__global__ void k_fast_scan_caps_done(FastCtl* ctl, int round, u32 vcap) {
+  if (ctl->scan_n[round] == 0u) ctl->n_visits[round] = 0u;
+  if (ctl->n_visits[round] > vcap) {
+    ctl->n_visits[round] = 0u;
     ctl->overflow = 1u;
   }
 }
 
 // did the relaxation produce the frame's result?  (round 0 settled; if it grew lists, round 1 settled too, its lists fit, and
 // nobody is at the end of a list shorter than its walk)
+// the last round that ran
+__device__ __forceinline__ int fast_last_round(const FastCtl* ctl) {
+  int last = 0;
+  for (int r = 1; r < kFastMaxRounds; ++r)
+    if (ctl->grew[r]) last = r;
+  return last;
+}
 __device__ __forceinline__ bool fast_solved(const FastCtl* ctl) {
-  if (ctl->overflow || ctl->settled[0] == 0u) return false;
-  if (ctl->grew == 0u) return ctl->want_more[0] == 0u;
-  return ctl->settled[1] != 0u && ctl->want_more[1] == 0u;
+  if (ctl->overflow) return false;
+  const int last = fast_last_round(ctl);
+  return ctl->settled[last] != 0u && ctl->want_more[last] == 0u;
 }
 // The relaxation did not produce the result (a ray outgrew its round-1 list -- once in a few hundred frames of the benchmark
 // stream with cap1 = cap0, never seen with cap1 = 4 cap0 --, lists that do not fit, a barrier that gave up): ONE lane runs the
@@ -539,17 +549,25 @@ __global__ void __launch_bounds__(64) k_fast_sequential(const FrameParams* __res
 __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V0, FastVisits V1, const u32* reach, u64* __restrict__ table_obs, const FastCtl* ctl,
                                                          u32 vcap0, u32 vcap1, u32* __restrict__ stats) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // run totals (cox_integrator_fast_stats): how often the relaxation was not enough, and how much of it there was
+    const int last = fast_last_round(ctl);
+    bool aborted = false;
+    u32 later_passes = 0;
+    for (int r = 0; r < kFastMaxRounds; ++r) {
+      aborted |= ctl->bar[r].abort != 0u;
+      if (r > 0) later_passes += ctl->passes[r];
+    }
     if (ctl->sequential) atomicAdd(&stats[0], 1u);
-    if (ctl->sequential && ctl->settled[0] && ctl->grew && ctl->settled[1] && ctl->want_more[1]) atomicAdd(&stats[4], 1u);  // ... because a ray outgrew its round-1 list
-    if (ctl->sequential && (ctl->bar[0].abort || ctl->bar[1].abort)) atomicAdd(&stats[5], 1u);                               // ... because a barrier gave up
-    if (ctl->grew) atomicAdd(&stats[1], 1u);
+    if (ctl->sequential && !ctl->overflow && ctl->settled[last] && ctl->want_more[last]) atomicAdd(&stats[4], 1u);  // ... because a ray outgrew its list in the last round
+    if (ctl->sequential && aborted) atomicAdd(&stats[5], 1u);                                                        // ... because a barrier gave up
+    if (ctl->grew[1]) atomicAdd(&stats[1], 1u);
+    if (last >= 2) atomicAdd(&stats[6], 1u);
     atomicAdd(&stats[2], ctl->passes[0]);
-    atomicAdd(&stats[3], ctl->passes[1]);
+    atomicAdd(&stats[3], later_passes);
   }
   if (ctl->sequential) return;  // the sequential kernel wrote the table as it went
-  const bool r1 = ctl->grew != 0u;
-  const FastVisits& V = r1 ? V1 : V0;
-  const u32 n = r1 ? min(ctl->n_visits[1], vcap1) : min(ctl->n_visits[0], vcap0);
+  const int last = fast_last_round(ctl);
+  const FastVisits& V = last ? V1 : V0;
+  const u32 n = last ? min(ctl->n_visits[last], vcap1) : min(ctl->n_visits[0], vcap0);
   // thread = performed visit: it is its slot's last one unless a later visit of the run is performed too (walking FORWARD from the
   // performed visits: the runs of nothing but unperformed visits -- the voxels in front of the surfaces -- cost nothing)
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

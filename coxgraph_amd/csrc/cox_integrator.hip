@@ -43,20 +43,21 @@ using namespace cox;
 // device side
 // =================================================================================================
 // per-frame control words of the observed-set solve of the fast integrator (cox_fast.hpp; part of Counters, zeroed with it at frame start)
+constexpr int kFastMaxRounds = 8;
 struct FastCtl {
-  u32 n_visits[2];   // candidate visits of round 0 (cap0 per ray) / round 1 (sum of the grown lists; 0 = no round 1)
-  u32 settled[2];    // [round]: the relaxation reached a pass that moved nothing
-  u32 want_more[2];  // [round]: at that fixed point some ray is at the end of a list shorter than its walk, unstopped
-  u32 passes[2];     // [round]: passes the relaxation took
-  u32 grew;          // round 1 runs (k_fast_grow gave some ray its whole walk)
-  u32 n_long;        // round 1: rays with a list longer than cap1 (one wave each)
-  u32 scan_n;        // rays the cap scan of round 1 covers (0 = no round 1)
+  u32 n_visits[kFastMaxRounds];   // candidate visits of round 0 (cap0 per ray) / of a later round (sum of the grown lists; 0 = the round does not run)
+  u32 settled[kFastMaxRounds];    // [round]: the relaxation reached a pass that moved nothing
+  u32 want_more[kFastMaxRounds];  // [round]: at that fixed point some ray is at the end of a list shorter than its walk, unstopped
+  u32 passes[kFastMaxRounds];     // [round]: passes the relaxation took
+  u32 grew[kFastMaxRounds];       // [round >= 1]: the round runs (k_fast_grow gave some ray its whole walk)
+  u32 scan_n[kFastMaxRounds];     // [round >= 1]: rays the cap scan of the round covers (0 = the round does not run)
+  u32 n_long;        // rays with a list longer than cap1 (one wave each), over all rounds
   u32 overflow;      // lists that do not fit their buffers
   u32 sequential;    // the sequential kernel produced this frame's result (k_fast_sequential)
-  u32 pad[3];
+  u32 pad[5];
   struct Bar {
     u32 arrived, pad0[15], epoch, pad1[15], moved[3], want[3], abort, pad2[9];
-  } bar[2];
+  } bar[kFastMaxRounds];
 };
 struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_valid;      // points that passed isPointValid
@@ -1210,6 +1211,7 @@ struct FastState {
   int fences = 1;                 // COX_FAST_FENCE (experiments): release / acquire fences in the relaxation's barrier
   u32 relax_groups = kFastRelaxGroups;  // COX_FAST_GROUPS (experiments): workgroups of the relaxation (all resident at once: far fewer than the chip holds)
   bool force_sequential = false;  // COX_FAST_SEQUENTIAL=1 (tests): every frame is redone by k_fast_sequential
+  int rounds = 2;               // rounds of list growth + relaxation enqueued per frame (2 at coarse voxels, 4 where rays are long in voxels; COX_FAST_ROUNDS)
   u32 cap0 = 8, cap1 = 16;      // candidate steps per ray in round 0; list length of the rays that did not get their whole walk in round 1
   u32* d_stats = nullptr;       // [8] run totals: frames redone by the sequential kernel, frames with a round 1, passes of the relaxation (round 0, round 1), ...
   u64 off_start = 0, off_obs = 0;  // ApproxHashSet::offset_
@@ -1328,8 +1330,12 @@ struct cox_integrator {
   uint8_t* own_rgba[kStageSets] = {};
   u32* depth_flag = nullptr;  // depth front end: valid pixels per tile
   u32* d_depth_n = nullptr;   // [kStageSets] point count of the depth image converted into each staging set: it stays on the device
-  // the engine's own input stream: H2D copies of host buffers (cox_integrate_points_async) run here, beside the kernels of earlier frames
-  hipStream_t st_in = nullptr;
+  // Host inputs (cox_integrate_points_async, cox_integrate_depth_async) are copied on the ray-generation stream of the frame they
+  // belong to -- with the default stream map that is the OTHER ray-generation stream than the previous frame's, so the copy of
+  // frame t + 1 still runs beside the kernels of frame t.  A stream of their own was tried first and fell off the cliff every fifth
+  // stream falls off (merged 6 500 -> 1 640 frames/s with the extra stream).
+  float* own_depth[kStageSets] = {};       // staging for host depth images (cox_integrate_depth_async)
+  uint8_t* own_depth_rgba[kStageSets] = {};
   hipEvent_t in_ready[kStageSets] = {};  // staging set k has been filled (the frame's first stage waits for it)
   hipEvent_t in_free[kStageSets] = {};   // the frame that read staging set k last has read it for the last time
   bool in_used[kStageSets] = {};
@@ -1407,7 +1413,6 @@ static int sync_all(cox_integrator* I) {
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
   if (I->st_alt) COX_HIP(hipStreamSynchronize(I->st_alt));
-  if (I->st_in) COX_HIP(hipStreamSynchronize(I->st_in));
   return COX_OK;
 }
 
@@ -1455,6 +1460,8 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
   for (int k = 0; k < kStageSets; ++k) {
     COX_TRY(dev_realloc(&I->own_xyz[k], static_cast<size_t>(cap) * 3));
     COX_TRY(dev_realloc(&I->own_rgba[k], static_cast<size_t>(cap) * 4));
+    COX_TRY(dev_realloc(&I->own_depth[k], cap));
+    COX_TRY(dev_realloc(&I->own_depth_rgba[k], static_cast<size_t>(cap) * 4));
   }
   COX_TRY(dev_realloc(&I->depth_flag, cap));
   COX_TRY(alloc_sort_ws(&I->sort_pts, cap));
@@ -2007,10 +2014,10 @@ static int fast_front(const StageCtx& c, FastJob* job) {
     TimedRegion t(I, COX_KC_FAST_VISITS, s);
     if (I->small_axis_cap)
       hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V0.vhash, V0.key[0], V0.val[0], V0.vray, V0.voff, X.cap[c.slot],
-                         X.cap0, V0.cap, F.cnt);
+                         X.cap0, 0, F.cnt);
     else
       hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V0.vhash, V0.key[0], V0.val[0], V0.vray, V0.voff, X.cap[c.slot],
-                         X.cap0, V0.cap, F.cnt);
+                         X.cap0, 0, F.cnt);
     V0.sorted = radix_sort_pairs<11>(V0.key[0], V0.val[0], V0.key[1], V0.val[1], &F.cnt->fast.n_visits[0], V0.cap, std::min<u32>(V0.cap, 1u << 19), kFastSlotBits + 1,
                                      false, 2, I->sort_vis, nullptr, s);
     hipLaunchKernelGGL(k_fast_inverse, dim3(512), dim3(256), 0, s, V0.key[V0.sorted], V0.val[V0.sorted], V0.vray, V0.vhash, V0.voff, V0.pos_of, V0.sinfo, V0.shash,
@@ -2039,28 +2046,29 @@ static int fast_solve(const StageCtx& c, const FastJob& job) {
     hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V0), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, 0, X.cap0,
                        X.long_list, n_rays, X.fences);
   }
-  {
+  for (int round = 1; round < X.rounds; ++round) {
     // round 1 (every kernel returns at once when round 0 left nobody at the end of a capped list): whole walks for those rays, all
-    // lists sorted again, relaxation from round 0's fixed point
+    // lists sorted again, relaxation from round 0's fixed point; further rounds (fine voxels: COX_FAST_ROUNDS) the same for the rays
+    // that have outgrown their lists since
     TimedRegion t(I, COX_KC_FAST_ROUND1, s);
-    hipLaunchKernelGGL(k_fast_grow, gr, dim3(256), 0, s, F.rays.nsteps, cap, reach, ctl, X.cap1, X.long_list, n_rays);
+    hipLaunchKernelGGL(k_fast_grow, gr, dim3(256), 0, s, F.rays.nsteps, cap, reach, ctl, round, X.cap1, X.long_list, n_rays);
     if (I->pcap <= (1u << 15)) {
-      hipLaunchKernelGGL(k_fast_scan_caps, dim3(1), dim3(1024), 0, s, cap, V1.voff, ctl, I->pcap, V1.cap);
+      hipLaunchKernelGGL(k_fast_scan_caps, dim3(1), dim3(1024), 0, s, cap, V1.voff, ctl, round, I->pcap, V1.cap);
     } else {  // (rays by the hundred thousand: the three-launch scan; it covers scan_n rays, none without growth)
-      exclusive_scan_u32(cap, V1.voff, &ctl->scan_n, I->pcap, I->pcap, &ctl->n_visits[1], I->scanws_f, s);
-      hipLaunchKernelGGL(k_fast_scan_caps_done, dim3(1), dim3(1), 0, s, ctl, V1.cap);
+      exclusive_scan_u32(cap, V1.voff, &ctl->scan_n[round], I->pcap, I->pcap, &ctl->n_visits[round], I->scanws_f, s);
+      hipLaunchKernelGGL(k_fast_scan_caps_done, dim3(1), dim3(1), 0, s, ctl, round, V1.cap);
     }
     if (I->small_axis_cap)
-      hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V1.vhash, V1.key[0], V1.val[0], V1.vray, V1.voff, cap, 0u, V1.cap,
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapSmall>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V1.vhash, V1.key[0], V1.val[0], V1.vray, V1.voff, cap, 0u, round,
                          F.cnt);
     else
-      hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V1.vhash, V1.key[0], V1.val[0], V1.vray, V1.voff, cap, 0u, V1.cap,
+      hipLaunchKernelGGL(k_fast_visits<kAxisCapLarge>, gw, dim3(256), 0, s, F.d_params, FF, F.rays, V1.vhash, V1.key[0], V1.val[0], V1.vray, V1.voff, cap, 0u, round,
                          F.cnt);
-    V1.sorted = radix_sort_pairs<11>(V1.key[0], V1.val[0], V1.key[1], V1.val[1], &ctl->n_visits[1], V1.cap, std::min<u32>(V1.cap, 1u << 19), kFastSlotBits + 1, false, 2,
-                                     I->sort_vis1, nullptr, s);
+    V1.sorted = radix_sort_pairs<11>(V1.key[0], V1.val[0], V1.key[1], V1.val[1], &ctl->n_visits[round], V1.cap, std::min<u32>(V1.cap, 1u << 19), kFastSlotBits + 1, false,
+                                     2, I->sort_vis1, nullptr, s);
     hipLaunchKernelGGL(k_fast_inverse, dim3(512), dim3(256), 0, s, V1.key[V1.sorted], V1.val[V1.sorted], V1.vray, V1.vhash, V1.voff, V1.pos_of, V1.sinfo, V1.shash,
-                       &ctl->n_visits[1], V1.cap);
-    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V1), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, 1, X.cap1,
+                       &ctl->n_visits[round], V1.cap);
+    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V1), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, round, X.cap1,
                        X.long_list, n_rays, X.fences);
   }
   // (the relaxation packs (ray, step) into one word: a configuration whose walks or ray counts do not fit takes the sequential kernel)
@@ -2443,6 +2451,11 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     if (method == COX_METHOD_FAST) {
       I->n_streams = fast_mode == 1 ? 1 : 3;
       if (const char* e = std::getenv("COX_FAST_FENCE")) I->fast.fences = std::atoi(e);
+      // At 5 cm two rounds settle every frame of the benchmark stream; at 2 cm and 1 cm nine frames in ten have a ray that outgrows its
+      // round-1 list (more rays per surface patch, longer second-order chains), and a frame that ends so is redone by ONE lane
+      // (14 and 4 frames/s): four rounds there -- the extra launches are nothing next to frames of a millisecond and more.
+      I->fast.rounds = ((max_steps_per_ray(I) - 1) / 3 + 2 <= kAxisCapSmall) ? 2 : kFastMaxRounds;
+      if (const char* e = std::getenv("COX_FAST_ROUNDS")) I->fast.rounds = std::min(kFastMaxRounds, std::max(2, std::atoi(e)));
       if (const char* e = std::getenv("COX_FAST_GROUPS")) I->fast.relax_groups = static_cast<u32>(std::min(256, std::max(8, std::atoi(e))));
       I->fast.force_sequential = std::getenv("COX_FAST_SEQUENTIAL") && std::atoi(std::getenv("COX_FAST_SEQUENTIAL")) != 0;
       if (const char* e = std::getenv("COX_FAST_CAP")) {  // candidate steps per ray: "cap0" or "cap0,cap1"
@@ -2466,7 +2479,6 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     if (st == COX_OK && hipEventCreateWithFlags(&I->in_ready[k], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
     ev(&I->in_free[k]);
   }
-  if (st == COX_OK && hipStreamCreateWithFlags(&I->st_in, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
   ev(&I->ev_producer);
   ev(&I->ev_inputs_read);
   I->layer_generation = layer->generation;
@@ -2636,7 +2648,10 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     if (I->in_ready[k]) (void)hipEventDestroy(I->in_ready[k]);
     if (I->in_free[k]) (void)hipEventDestroy(I->in_free[k]);
   }
-  if (I->st_in) (void)hipStreamDestroy(I->st_in);
+  for (int k = 0; k < kStageSets; ++k) {
+    if (I->own_depth[k]) (void)hipFree(I->own_depth[k]);
+    if (I->own_depth_rgba[k]) (void)hipFree(I->own_depth_rgba[k]);
+  }
   if (I->h_params) (void)hipHostFree(I->h_params);
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
@@ -2663,9 +2678,9 @@ int cox_integrate_points_ex(cox_integrator_t* I, const float T_G_C[7], const flo
   return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 1);
 }
 
-// Host buffers -> staging set k of the frame about to be enqueued, on the input stream, without waiting for anything but the
-// staging set itself: the copy of frame t + 1 runs beside the kernels of frame t.  Pageable memory goes through a pinned bounce
-// buffer (one CPU copy; the caller's buffer is free again when the call returns), pinned memory is copied from directly.
+// Host buffers -> staging set k of the frame about to be enqueued, on that frame's ray-generation stream, without waiting for
+// anything but the staging set itself.  Pageable memory goes through a pinned bounce buffer (one CPU copy; the caller's buffer is
+// free again when the call returns), pinned memory is copied from directly.
 static bool host_pointer_is_pinned(const void* p) {
   hipPointerAttribute_t a;
   const hipError_t e = hipPointerGetAttributes(&a, p);
@@ -2675,13 +2690,17 @@ static bool host_pointer_is_pinned(const void* p) {
   }
   return a.type == hipMemoryTypeHost;
 }
-static int stage_host_inputs(cox_integrator* I, int k, const float* xyz, const uint8_t* rgba, u32 n, FrameInput* in) {
+// the stream the next frame's first stage will run on
+static inline hipStream_t next_input_stream(const cox_integrator* I) { return stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets)); }
+// two host arrays (a: a_bytes per element, b: b_bytes per element or absent) -> the device buffers dst_a / dst_b
+static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_bytes, void* dst_a, const void* b, size_t b_bytes, void* dst_b, u32 n, FrameInput* in) {
+  const hipStream_t s_in = next_input_stream(I);
   // the staging set is free once the frame that used it three frames ago has read it for the last time; that frame's stages
   // H .. M are enqueued by the caller's thread, so the event is recorded by now
-  if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(I->st_in, I->in_free[k], 0));
-  const bool pinned = host_pointer_is_pinned(xyz) && (!rgba || host_pointer_is_pinned(rgba));
-  const float* src_xyz = xyz;
-  const uint8_t* src_rgba = rgba;
+  if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s_in, I->in_free[k], 0));
+  const bool pinned = host_pointer_is_pinned(a) && (!b || host_pointer_is_pinned(b));
+  const void* src_a = a;
+  const void* src_b = b;
   if (!pinned) {
     if (I->pin_cap < I->pcap) {
       COX_TRY(sync_all(I));
@@ -2701,16 +2720,16 @@ static int stage_host_inputs(cox_integrator* I, int k, const float* xyz, const u
     }
     // the bounce buffer's previous copy (three frames ago) has left it: in_ready[k] was recorded behind that copy
     if (I->in_used[k]) COX_HIP(hipEventSynchronize(I->in_ready[k]));
-    memcpy(I->pin_xyz[k], xyz, sizeof(float) * 3 * n);
-    if (rgba) memcpy(I->pin_rgba[k], rgba, 4ull * n);
-    src_xyz = I->pin_xyz[k];
-    src_rgba = rgba ? I->pin_rgba[k] : nullptr;
+    memcpy(I->pin_xyz[k], a, a_bytes * n);
+    if (b) memcpy(I->pin_rgba[k], b, b_bytes * n);
+    src_a = I->pin_xyz[k];
+    src_b = b ? I->pin_rgba[k] : nullptr;
   }
-  COX_HIP(hipMemcpyAsync(I->own_xyz[k], src_xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st_in));
-  if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], src_rgba, 4ull * n, hipMemcpyHostToDevice, I->st_in));
-  COX_HIP(hipEventRecord(I->in_ready[k], I->st_in));
+  COX_HIP(hipMemcpyAsync(dst_a, src_a, a_bytes * n, hipMemcpyHostToDevice, s_in));
+  if (b) COX_HIP(hipMemcpyAsync(dst_b, src_b, b_bytes * n, hipMemcpyHostToDevice, s_in));
+  COX_HIP(hipEventRecord(I->in_ready[k], s_in));
   I->in_used[k] = true;
-  in->ready = I->in_ready[k];
+  in->ready = nullptr;  // (same stream as the frame's first stage: stream order)
   in->consumed = I->in_free[k];
   return COX_OK;
 }
@@ -2725,12 +2744,12 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);  // the bundle set of the frame about to be enqueued
   FrameInput in;
   if (n) {  // synchronous call: copied straight from the caller's buffers (the runtime stages pageable memory itself), the call returns after the frame
-    if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(I->st_in, I->in_free[k], 0));
-    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, I->st_in));
-    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, I->st_in));
-    COX_HIP(hipEventRecord(I->in_ready[k], I->st_in));
+    const hipStream_t s_in = next_input_stream(I);
+    if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s_in, I->in_free[k], 0));
+    COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, s_in));
+    if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, s_in));
+    COX_HIP(hipEventRecord(I->in_ready[k], s_in));
     I->in_used[k] = true;
-    in.ready = I->in_ready[k];
     in.consumed = I->in_free[k];
   }
   COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, true, in));
@@ -2746,7 +2765,7 @@ int cox_integrate_points_async(cox_integrator_t* I, const float T_G_C[7], const 
   if (I->submitter) I->submitter->wait_outstanding(1);
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
   FrameInput in;
-  if (n) COX_TRY(stage_host_inputs(I, k, xyz, rgba, static_cast<u32>(n), &in));
+  if (n) COX_TRY(stage_host_inputs(I, k, xyz, sizeof(float) * 3, I->own_xyz[k], rgba, 4, I->own_rgba[k], static_cast<u32>(n), &in));
   // (the staging buffers are the engine's own: no ordering against the caller's stream for them)
   const bool producer = I->has_producer;
   I->has_producer = false;
@@ -2760,8 +2779,19 @@ int cox_integrator_wait_inputs(cox_integrator_t* I) {
   if (!I) return COX_ERR_INVALID_ARG;
   if (I->proj) return COX_OK;  // (the projective integrator's host entry point is synchronous)
   COX_HIP(hipSetDevice(I->layer->device));
-  if (I->st_in) COX_HIP(hipStreamSynchronize(I->st_in));
+  for (int k = 0; k < kStageSets; ++k)
+    if (I->in_used[k]) COX_HIP(hipEventSynchronize(I->in_ready[k]));
   return COX_OK;
+}
+
+// depth image (device) -> point list in staging set k on stream s; the point count lands in d_depth_n[k]
+static void convert_depth(cox_integrator* I, int k, const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4], hipStream_t s) {
+  const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
+  const dim3 gt(std::max<u32>(1, (n + kDepthTile - 1) / kDepthTile));
+  u32* tile_sums = I->depth_flag + static_cast<size_t>(k) * (I->pcap / kDepthTile + 1);  // one set per staging set: consecutive frames convert on different streams
+  hipLaunchKernelGGL(k_depth_count, gt, dim3(256), 0, s, depth_dev, n, tile_sums);
+  hipLaunchKernelGGL(k_depth_points, gt, dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], tile_sums, I->own_xyz[k], I->own_rgba[k],
+                     I->d_depth_n + k);
 }
 
 int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h, const float K[4]) {
@@ -2772,20 +2802,17 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
   // Frames stay in flight and nothing comes back to the host: the point list goes to the staging set of the frame's bundle set
-  // (read by its stages H .. M), converted on the engine's input stream, and the point count -- which the "mixed" visiting order
-  // is a function of -- stays in device memory: the frame's first kernel takes it from there (k_bundle_insert / k_params_count).
+  // (read by its stages H .. M), converted on the frame's ray-generation stream, and the point count -- which the "mixed" visiting
+  // order is a function of -- stays in device memory: the frame's first kernel takes it from there (k_bundle_insert / k_params_count).
   if (I->submitter) I->submitter->wait_outstanding(1);
   const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
-  const hipStream_t s = I->st_in;
+  const hipStream_t s = next_input_stream(I);
   if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s, I->in_free[k], 0));
   if (I->has_producer) {  // the images were written on the caller's stream
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
     COX_HIP(hipStreamWaitEvent(s, I->ev_producer, 0));
   }
-  const dim3 gt(std::max<u32>(1, (n + kDepthTile - 1) / kDepthTile));
-  hipLaunchKernelGGL(k_depth_count, gt, dim3(256), 0, s, depth_dev, n, I->depth_flag);
-  hipLaunchKernelGGL(k_depth_points, gt, dim3(256), 0, s, depth_dev, rgba_dev, w, h, K[0], K[1], K[2], K[3], I->depth_flag, I->own_xyz[k], I->own_rgba[k],
-                     I->d_depth_n + k);
+  convert_depth(I, k, depth_dev, rgba_dev, w, h, K, s);
   if (I->has_producer) {  // the images are not read after this: later work on the caller's stream may overwrite / free them
     COX_HIP(hipEventRecord(I->ev_inputs_read, s));
     COX_HIP(hipStreamWaitEvent(I->producer, I->ev_inputs_read, 0));
@@ -2793,10 +2820,29 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   COX_HIP(hipEventRecord(I->in_ready[k], s));
   I->in_used[k] = true;
   FrameInput in;
-  in.ready = I->in_ready[k];
   in.consumed = I->in_free[k];
   in.n_dev = I->d_depth_n + k;
   // (the staging buffers are the engine's own: no producer ordering for them)
+  const bool producer = I->has_producer;
+  I->has_producer = false;
+  const int st = integrate_device(I, T_G_C, I->own_xyz[k], I->own_rgba[k], n, 0, false, in);
+  I->has_producer = producer;
+  return st;
+}
+
+int cox_integrate_depth_async(cox_integrator_t* I, const float T_G_C[7], const float* depth, const uint8_t* rgba, int w, int h, const float K[4]) {
+  COX_ENTRY_NO_DRAIN();
+  if (!I || !T_G_C || !depth || !K || w <= 0 || h <= 0 || static_cast<uint64_t>(w) * h > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  if (I->proj) return COX_ERR_UNSUPPORTED;
+  COX_HIP(hipSetDevice(I->layer->device));
+  const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
+  COX_TRY(ensure_capacity(I, n));
+  if (I->submitter) I->submitter->wait_outstanding(1);
+  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
+  FrameInput in;
+  COX_TRY(stage_host_inputs(I, k, depth, sizeof(float), I->own_depth[k], rgba, 4, I->own_depth_rgba[k], n, &in));
+  convert_depth(I, k, I->own_depth[k], rgba ? I->own_depth_rgba[k] : nullptr, w, h, K, next_input_stream(I));
+  in.n_dev = I->d_depth_n + k;
   const bool producer = I->has_producer;
   I->has_producer = false;
   const int st = integrate_device(I, T_G_C, I->own_xyz[k], I->own_rgba[k], n, 0, false, in);
@@ -2911,7 +2957,7 @@ int cox_integrator_host_time(cox_integrator_t* I, double* ms_total, uint64_t* fr
   return COX_OK;
 }
 
-int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[7]) {
+int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[8]) {
   COX_ENTRY();
   if (!I || !out) return COX_ERR_INVALID_ARG;
   if (I->method != COX_METHOD_FAST || I->proj) return COX_ERR_UNSUPPORTED;
@@ -2923,6 +2969,7 @@ int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[7]) {
   out[4] = I->fast.frames;
   out[5] = h[4];
   out[6] = h[5];
+  out[7] = h[6];
   return COX_OK;
 }
 

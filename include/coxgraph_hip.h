@@ -178,8 +178,8 @@ int cox_integrate_points_ex(cox_integrator_t* integ, const float T_G_C[7], const
 int cox_integrate_points_dev(cox_integrator_t* integ, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace);
 /* TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace_points) as the reference calls it -- with HOST
  * buffers (coxgraph/include/coxgraph/map_comm/tsdf_recover.h:71-77) -- without waiting for the frame: the buffers are copied to
- * one of three staging sets on the engine's own input stream (the copy of frame t+1 runs beside the kernels of frame t) and the
- * frame is enqueued behind the copy.  Pageable buffers are free again when the call returns (they go through a pinned bounce
+ * one of three staging sets on the stream the frame's ray generation runs on (with the default stream map the copy of frame t+1
+ * runs beside the kernels of frame t) and the frame is enqueued behind the copy.  Pageable buffers are free again when the call returns (they go through a pinned bounce
  * buffer: one CPU copy); buffers in pinned memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor after pin_memory()) are
  * copied from directly and must stay unmodified until cox_integrator_wait_inputs or cox_integrator_sync has returned.
  * Errors of the frame are reported by the next cox_integrator_sync, as for the *_dev entry points. */
@@ -193,6 +193,10 @@ int cox_integrator_wait_inputs(cox_integrator_t* integ);
  * kernel reads it from device memory), so frames stay in flight exactly as with cox_integrate_points_dev. */
 int cox_integrate_depth_dev(cox_integrator_t* integ, const float T_G_C[7], const float* depth_dev, const uint8_t* rgba_dev, int w, int h,
                             const float K[4]);
+/* the same from HOST images (what a depth camera driver hands over), without waiting for the frame: depth (w*h floats, metres) and
+ * rgba (w*h*4 bytes or NULL) are copied like the buffers of cox_integrate_points_async (pageable: free again on return; pinned:
+ * unmodified until cox_integrator_wait_inputs), converted on the GPU and integrated. */
+int cox_integrate_depth_async(cox_integrator_t* integ, const float T_G_C[7], const float* depth, const uint8_t* rgba, int w, int h, const float K[4]);
 /* hip_stream: the hipStream_t (as void*) the caller produces *_dev inputs on; NULL = the legacy default stream.
  * enable = 0 returns to contract (a) above. */
 int cox_integrator_set_input_stream(cox_integrator_t* integ, void* hip_stream, int enable);
@@ -237,9 +241,10 @@ int cox_integrator_class_times(cox_integrator_t* integ, double ms[COX_KERNEL_CLA
 /* method "fast" only (COX_ERR_UNSUPPORTED otherwise): run totals of the observed-set relaxation since the integrator was created --
  * out[0] frames the relaxation did not settle and that were redone by the sequential kernel (exact either way), out[1] frames that
  * needed a second round (some ray got through its capped candidate list), out[2] / out[3] passes of the relaxation in round 0 /
- * round 1, out[4] frames, out[5] the part of out[0] in which a ray outgrew its round-1 list, out[6] the part in which a grid
- * barrier gave up.  No reference counterpart (measurement only).  Waits for the frames in flight. */
-int cox_integrator_fast_stats(cox_integrator_t* integ, uint64_t out[7]);
+ * the later rounds, out[4] frames, out[5] the part of out[0] in which a ray outgrew its list in the last round, out[6] the part in
+ * which a grid barrier gave up, out[7] frames that needed a third round or more.  No reference counterpart (measurement only).
+ * Waits for the frames in flight. */
+int cox_integrator_fast_stats(cox_integrator_t* integ, uint64_t out[8]);
 
 /* self-test: the merged integrator evaluates its sequential mean with an IEEE division whose divisor-only part is
  * hoisted out of the dependent chain; this compares it bit for bit with the compiler's '/' on n pseudo-random operand

@@ -38,5 +38,13 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     st = integ.fast_stats() if method == "fast" else {}
     hm, hf = integ.host_time()
+    if rep == 1 and method == "fast":  # class times, one frame in flight
+        integ.set_profiling(True)
+        integ.class_times(reset=True)
+        for T, x, c, k in frames[10:50]:
+            integ.integrate_points_dev(T, x.data_ptr(), c.data_ptr(), k)
+            integ.sync()
+        ct = integ.class_times()
+        print("  class ms/frame (one frame in flight):", {k: round(v[0] / 40, 4) for k, v in ct.items() if v[1]}, flush=True)
     print(f"{method} voxel {voxel} env {({k: v for k, v in os.environ.items() if k.startswith('COX_')})}: {(n - 10) / dt:.0f} frames/s, host {hm / max(hf, 1):.3f} ms/frame, {st}", flush=True)
     del integ, layer

@@ -670,8 +670,12 @@ def test_depth_stream_without_host_sync(hip, method):
     depths = [torch.from_numpy(d).cuda() for _, _, _, d in frames]
     empty = torch.zeros((480, 640), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    for t, ((T, _, _, _), d) in enumerate(zip(frames, depths)):
-        ia.integrate_depth_dev(T, d.data_ptr(), colors.data_ptr(), 640, 480, K)
+    host_colors = synth.frame_colors()
+    for t, ((T, _, _, dh), d) in enumerate(zip(frames, depths)):
+        if t % 3 == 2:  # every third frame as HOST images (cox_integrate_depth_async: staged, converted, count on the device)
+            ia.integrate_depth_async(T, dh.ctypes.data, host_colors.ctypes.data, 640, 480, K)
+        else:
+            ia.integrate_depth_dev(T, d.data_ptr(), colors.data_ptr(), 640, 480, K)
         if t == 5:
             ia.integrate_depth_dev(T, empty.data_ptr(), colors.data_ptr(), 640, 480, K)
     ia.sync()
