@@ -496,6 +496,22 @@ class Registration:
         self.eng.check(self.eng.fn("reg_kernel_time")(self.h, C.byref(ms), C.byref(n), C.c_int(int(reset))), "reg_kernel_time")
         return float(ms.value), int(n.value)
 
+    @staticmethod
+    def normal_eq_batch(regs, poses_ref, poses_read):
+        """cox_reg_normal_eq_batch: all the constraints of one pose-graph evaluation in ONE launch (every handle with its stored
+        samples, or all its points).  -> [(H 8x8, b 8, cost, n_corr)] in the order of `regs`."""
+        n = len(regs)
+        eng = regs[0].eng
+        handles = (C.c_void_p * n)(*[r.h for r in regs])
+        pr = np.ascontiguousarray(poses_ref, np.float64).reshape(n, 4)
+        pd = np.ascontiguousarray(poses_read, np.float64).reshape(n, 4)
+        H = np.zeros((n, 8, 8), np.float64)
+        b = np.zeros((n, 8), np.float64)
+        cost = np.zeros(n, np.float64)
+        nc = np.zeros(n, np.uint64)
+        eng.check(eng.fn("reg_normal_eq_batch")(handles, C.c_uint64(n), _fp(pr), _fp(pd), _fp(H), _fp(b), _fp(cost), _fp(nc)), "reg_normal_eq_batch")
+        return [(H[c], b[c], float(cost[c]), int(nc[c])) for c in range(n)]
+
 
 class MeshMsgStruct(C.Structure):
     """cox_mesh_msg."""

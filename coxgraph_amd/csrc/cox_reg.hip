@@ -245,17 +245,17 @@ __global__ void __launch_bounds__(256) k_reg_scale(double* __restrict__ a, size_
 // ---- fused normal equations ----------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, RelPose P, const float* __restrict__ pts, const u32* __restrict__ sample_idx,
-                                                               u32 n_res, double no_corr_cost, double* partials /*[grid][256]*/, double* __restrict__ out /*[256]*/,
-                                                               u32* ticket) {
+// (bx of nb: this workgroup's place among the workgroups of ITS constraint -- the whole grid for one constraint, a row of it in a batch)
+__device__ __forceinline__ void reg_normal_eq_body(const ReadingView& L, const RelPose& P, const float* __restrict__ pts, const u32* __restrict__ sample_idx, u32 n_res,
+                                                   double no_corr_cost, double* partials /*[nb][256]*/, double* __restrict__ out /*[256]*/, u32* ticket, u32 bx, u32 nb) {
   __shared__ double X[kRegThreads / 64][16][68];  // per wave: 16 components x 64 points (rows padded to 68: conflict-free writes, 2-way reads)
   __shared__ double tile[kRegThreads / 64][256];
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
-  const u32 stride = gridDim.x * blockDim.x;
+  const u32 stride = nb * blockDim.x;
   const u32 n_iter = (n_res + stride - 1) / stride;
   for (u32 it = 0; it < n_iter; ++it) {
-    const u32 i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 i = it * stride + bx * blockDim.x + threadIdx.x;
     double x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = 0.0;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, Re
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][((lane >> 4) + 4 * r) * 16 + (lane & 15u)] = acc[r];
   __syncthreads();
-  partials[static_cast<size_t>(blockIdx.x) * kPartial + threadIdx.x] =
+  partials[static_cast<size_t>(bx) * kPartial + threadIdx.x] =
       ((tile[0][threadIdx.x] + tile[1][threadIdx.x]) + tile[2][threadIdx.x]) + tile[3][threadIdx.x];
   // the workgroup that finishes last sums the partials of all workgroups in workgroup order: same bits every run, and no
   // second launch (the one-workgroup reduction kernel took longer than this kernel)
@@ -294,14 +294,13 @@ __global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, Re
   __syncthreads();
   if (threadIdx.x == 0) {
     const u32 t = atomicAdd(ticket, 1u);
-    last = (t == gridDim.x - 1u) ? 1u : 0u;
+    last = (t == nb - 1u) ? 1u : 0u;
     if (last) *ticket = 0u;  // ready for the next launch on this stream
   }
   __syncthreads();
   if (!last) return;
   __threadfence();
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains; the order of the additions stays fixed
-  const u32 nb = gridDim.x;
   u32 bq = 0;
   for (; bq + 4 <= nb; bq += 4) {
     s0 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq) * kPartial + threadIdx.x]);
@@ -311,6 +310,32 @@ __global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, Re
   }
   for (; bq < nb; ++bq) s0 += __builtin_nontemporal_load(&partials[static_cast<size_t>(bq) * kPartial + threadIdx.x]);
   out[threadIdx.x] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq(ReadingView L, RelPose P, const float* __restrict__ pts, const u32* __restrict__ sample_idx,
+                                                               u32 n_res, double no_corr_cost, double* partials /*[grid][256]*/, double* __restrict__ out /*[256]*/,
+                                                               u32* ticket) {
+  reg_normal_eq_body(L, P, pts, sample_idx, n_res, no_corr_cost, partials, out, ticket, blockIdx.x, gridDim.x);
+}
+// ONE launch for all the registration constraints of a pose-graph evaluation (configs[4] evaluates 28 of them per solver iteration,
+// each a 15 us launch on a dozen workgroups of its own): blockIdx.y = constraint, its poses / pointers in a table in device memory,
+// one ticketed reduction per constraint.
+struct RegBatchEntry {
+  ReadingView L;
+  RelPose P;
+  const float* pts;
+  const u32* sample_idx;
+  double no_corr_cost;
+  u32 n_res, nb;  // residuals, workgroups of this constraint (<= gridDim.x)
+};
+__global__ void __launch_bounds__(kRegThreads) k_reg_normal_eq_batch(const RegBatchEntry* __restrict__ table, double* partials /*[n][gridDim.x][256]*/,
+                                                                     double* __restrict__ out /*[n][256]*/, u32* tickets /*[n]*/) {
+  const u32 c = blockIdx.y;
+  const u32 nb = table[c].nb;
+  if (blockIdx.x >= nb) return;
+  const RegBatchEntry E = table[c];
+  reg_normal_eq_body(E.L, E.P, E.pts, E.sample_idx, E.n_res, E.no_corr_cost, partials + static_cast<size_t>(c) * gridDim.x * kPartial, out + static_cast<size_t>(c) * kPartial,
+                     tickets + c, blockIdx.x, nb);
 }
 
 // ---- WeightedSampler<RegistrationPoint>::getRandomItem, reproducible and on the device ---------------------------------
@@ -396,6 +421,15 @@ struct cox_reg {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double ms = 0.0;
   uint64_t launches = 0;
+  bool stream_dirty = false;  // work enqueued on this handle's stream that a batch on another handle's stream has to wait for (sample draws / uploads)
+  // scratch of cox_reg_normal_eq_batch (owned by the batch's first handle)
+  RegBatchEntry* d_table = nullptr;
+  RegBatchEntry* h_table = nullptr;  // pinned
+  double* d_bpart = nullptr;
+  double* d_bout = nullptr;
+  double* h_bout = nullptr;  // pinned
+  u32* d_btickets = nullptr;
+  u64 batch_cap = 0, bpart_cap = 0;
 };
 
 template <typename T>
@@ -570,10 +604,12 @@ void cox_reg_destroy(cox_reg_t* G) {
   if (!G) return;
   (void)hipSetDevice(G->reading->device);
   if (G->stream) (void)hipStreamSynchronize(G->stream);
-  void* ptrs[] = {G->d_idx, G->d_stored, G->d_res, G->d_jf, G->d_jr, G->d_small, G->d_ticket};
+  void* ptrs[] = {G->d_idx, G->d_stored, G->d_res, G->d_jf, G->d_jr, G->d_small, G->d_ticket, G->d_table, G->d_bpart, G->d_bout, G->d_btickets};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (G->h_small) (void)hipHostFree(G->h_small);
+  if (G->h_table) (void)hipHostFree(G->h_table);
+  if (G->h_bout) (void)hipHostFree(G->h_bout);
   if (G->ev0) (void)hipEventDestroy(G->ev0);
   if (G->ev1) (void)hipEventDestroy(G->ev1);
   if (G->stream) (void)hipStreamDestroy(G->stream);
@@ -654,6 +690,7 @@ int cox_reg_draw_samples(cox_reg_t* G, uint64_t n_res, uint64_t seed) {
   COX_TRY(dev_grow(&G->d_stored, &G->stored_cap, std::max<uint64_t>(n_res, 1)));
   if (n_res) hipLaunchKernelGGL(k_draw_samples, dim3(static_cast<u32>((n_res + 255) / 256)), dim3(256), 0, s, R->cum, R->n, R->cum_total, seed, G->d_stored, n_res);
   COX_HIP(hipGetLastError());
+  G->stream_dirty = true;  // (a batch that runs on another handle's stream waits for the draw)
   G->has_stored = true;
   G->stored_samples = n_res;
   return COX_OK;
@@ -732,6 +769,91 @@ int cox_reg_normal_eq(cox_reg_t* G, const double pose_ref[4], const double pose_
   if (!G || !pose_ref || !pose_read || !H || !b || !cost) return COX_ERR_INVALID_ARG;
   COX_TRY(cox_reg_normal_eq_begin(G, pose_ref, pose_read, sample_idx, n_res));
   return cox_reg_normal_eq_finish(G, H, b, cost, n_corr);
+}
+
+int cox_reg_normal_eq_batch(cox_reg_t* const* regs, uint64_t n, const double* poses_ref, const double* poses_read, double* H, double* b, double* cost,
+                            uint64_t* n_corr) {
+  COX_ENTRY();
+  if (!regs || n == 0 || n > 65535 || !poses_ref || !poses_read || !H || !b || !cost) return COX_ERR_INVALID_ARG;
+  cox_reg* G0 = regs[0];
+  if (!G0) return COX_ERR_INVALID_ARG;
+  const int device = G0->reading->device;
+  for (uint64_t c = 0; c < n; ++c) {
+    const cox_reg* G = regs[c];
+    if (!G || G->pending || G->reading->device != device || G->ref->device != device) return COX_ERR_INVALID_ARG;  // one GPU per batch
+    const uint64_t nr = G->has_stored ? G->stored_samples : G->ref->n;
+    if (nr > 0x7FFFFFFFull) return COX_ERR_INVALID_ARG;
+  }
+  COX_HIP(hipSetDevice(device));
+  hipStream_t s = G0->stream;
+  if (G0->batch_cap < n) {
+    COX_HIP(hipStreamSynchronize(s));
+    if (G0->h_table) (void)hipHostFree(G0->h_table);
+    if (G0->h_bout) (void)hipHostFree(G0->h_bout);
+    for (void* p : {static_cast<void*>(G0->d_table), static_cast<void*>(G0->d_bout), static_cast<void*>(G0->d_btickets)})
+      if (p) (void)hipFree(p);
+    G0->h_table = nullptr, G0->h_bout = nullptr, G0->d_table = nullptr, G0->d_bout = nullptr, G0->d_btickets = nullptr, G0->batch_cap = 0;
+    const u64 cap = std::max<u64>(n, 32);
+    if (hipHostMalloc(reinterpret_cast<void**>(&G0->h_table), sizeof(RegBatchEntry) * cap, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&G0->h_bout), sizeof(double) * kPartial * cap, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&G0->d_table), sizeof(RegBatchEntry) * cap) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&G0->d_bout), sizeof(double) * kPartial * cap) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&G0->d_btickets), sizeof(u32) * cap) != hipSuccess) {
+      (void)hipGetLastError();
+      return COX_ERR_OUT_OF_MEMORY;
+    }
+    COX_HIP(hipMemset(G0->d_btickets, 0, sizeof(u32) * cap));  // every launch leaves them zero again
+    COX_HIP(hipDeviceSynchronize());
+    G0->batch_cap = cap;
+  }
+  u32 nb_max = 1;
+  for (uint64_t c = 0; c < n; ++c) {
+    cox_reg* G = regs[c];
+    const u32 nr = static_cast<u32>(G->has_stored ? G->stored_samples : G->ref->n);
+    const u32 nb = std::max<u32>(1, std::min<u32>(1024, (nr + kRegThreads - 1) / kRegThreads));  // (the same partition as a call of its own: same bits)
+    nb_max = std::max(nb_max, nb);
+    RegBatchEntry& E = G0->h_table[c];
+    E.L = reading_view(G->reading);
+    E.P = make_rel_pose(poses_ref + 4 * c, poses_read + 4 * c);
+    E.pts = G->ref->pts;
+    E.sample_idx = G->has_stored ? G->d_stored : nullptr;
+    E.no_corr_cost = G->no_corr_cost;
+    E.n_res = nr;
+    E.nb = nb;
+    if (G != G0 && G->stream_dirty) {  // its sample draw runs on its own stream
+      COX_HIP(hipStreamSynchronize(G->stream));
+      G->stream_dirty = false;
+    }
+    cox_layer_wait_writes(G->reading, s);  // frames still in flight on the reading layer
+  }
+  G0->stream_dirty = false;
+  COX_TRY(dev_grow(&G0->d_bpart, &G0->bpart_cap, static_cast<u64>(n) * nb_max * kPartial));
+  COX_HIP(hipMemcpyAsync(G0->d_table, G0->h_table, sizeof(RegBatchEntry) * n, hipMemcpyHostToDevice, s));
+  COX_HIP(hipEventRecord(G0->ev0, s));
+  hipLaunchKernelGGL(k_reg_normal_eq_batch, dim3(nb_max, static_cast<u32>(n)), dim3(kRegThreads), 0, s, G0->d_table, G0->d_bpart, G0->d_bout, G0->d_btickets);
+  COX_HIP(hipEventRecord(G0->ev1, s));
+  COX_HIP(hipMemcpyAsync(G0->h_bout, G0->d_bout, sizeof(double) * kPartial * n, hipMemcpyDeviceToHost, s));
+  COX_HIP(hipStreamSynchronize(s));
+  COX_HIP(hipGetLastError());
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, G0->ev0, G0->ev1) == hipSuccess) {
+    G0->ms += ms;
+    G0->launches += 1;
+  }
+  for (uint64_t c = 0; c < n; ++c) {
+    const double* D = G0->h_bout + kPartial * c;  // D[row * 16 + col] = sum_p x[row] x[col]
+    const double nr = static_cast<double>(G0->h_table[c].n_res);
+    const double sum_w = D[9 * 16 + 10];
+    const double scale = (sum_w > 0.0 && nr > 0.0) ? nr / sum_w : 0.0;
+    const double s2 = scale * scale;
+    for (int r = 0; r < 8; ++r) {
+      for (int q = 0; q < 8; ++q) H[64 * c + 8 * r + q] = nr > 0.0 ? D[r * 16 + q] * s2 : 0.0;
+      b[8 * c + r] = nr > 0.0 ? D[r * 16 + 8] * s2 : 0.0;
+    }
+    cost[c] = nr > 0.0 ? 0.5 * D[8 * 16 + 8] * s2 : 0.0;
+    if (n_corr) n_corr[c] = nr > 0.0 ? static_cast<uint64_t>(D[9 * 16 + 11] + 0.5) : 0;
+  }
+  return COX_OK;
 }
 
 int cox_reg_kernel_time(cox_reg_t* G, double* ms, uint64_t* launches, int reset) {

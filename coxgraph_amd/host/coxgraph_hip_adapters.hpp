@@ -359,6 +359,16 @@ class RegistrationCostFunction {
   // the same in two halves: a solver begins every constraint of an evaluation, then collects them (the kernels overlap)
   bool BeginNormalEquations(const double ref[4], const double read[4]) const { return cox_reg_normal_eq_begin(reg_, ref, read, nullptr, num_residuals()) == COX_OK; }
   bool FinishNormalEquations(double H[64], double b[8], double* cost) const { return cox_reg_normal_eq_finish(reg_, H, b, cost, nullptr) == COX_OK; }
+  // every constraint of one pose-graph evaluation in ONE launch (cox_reg_normal_eq_batch): costs[c] with poses ref[4c..] / read[4c..];
+  // each uses its drawn / set samples (or all its points).  All on one GPU.  H: 64 per constraint, b: 8, cost: 1.
+  static bool NormalEquationsBatch(const std::vector<const RegistrationCostFunction*>& costs, const double* ref, const double* read, double* H, double* b,
+                                   double* cost) {
+    std::vector<cox_reg_t*> regs;
+    for (const RegistrationCostFunction* c : costs) {
+      regs.push_back(c->reg_);
+    }
+    return cox_reg_normal_eq_batch(regs.data(), regs.size(), ref, read, H, b, cost, nullptr) == COX_OK;
+  }
 
  private:
   size_t n_ = 0;

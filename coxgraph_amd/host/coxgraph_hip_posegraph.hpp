@@ -5,9 +5,10 @@
 //   updateSubmapRPConstraints / optimize(enable_registration)   coxgraph/src/server/pose_graph_interface.cpp:10-105
 //   relative-pose residual  r = sqrt_information * e             coxgraph/include/coxgraph/server/backend/relative_pose_constraint.h:28-61,114-119
 //   node 0 constant, yaw as an angle                             pose_graph_interface.cpp:20-25, backend/node_collection.h:22-24
-//   solver budget: parameter_tolerance 3e-3                      backend/pose_graph.h:60-64
+//   ceres::Solve, parameter_tolerance 3e-3, 4 s budget           backend/pose_graph.h:56-68
 //
-// Ceres is replaced by a small dense Levenberg-Marquardt (the graphs have tens of nodes of 4 doubles); registration
+// Ceres itself is not in the image: its trust-region minimiser is restated in coxgraph_hip_solver.hpp (Solver::Options defaults +
+// the two values coxgraph overrides) on dense normal equations (the graphs have tens of nodes of 4 doubles); registration
 // constraints are evaluated in their fused form (8x8 normal equations per constraint), all of them begun before any is
 // collected.  The arithmetic is the same as coxgraph_amd/posegraph.py, operation for operation, so the two agree to
 // rounding (tests/test_host_logic.py compares them).
@@ -21,6 +22,7 @@
 
 #include <cstdio>
 
+#include "coxgraph_hip_solver.hpp"
 #include "coxgraph_hip_submap.hpp"
 
 namespace coxgraph_hip {
@@ -127,10 +129,8 @@ struct RegistrationConstraint {
 
 class PoseGraph {
  public:
-  struct Summary {
-    double initial_cost = 0.0, final_cost = 0.0;
-    int iterations = 0, evaluations = 0;
-  };
+  typedef TrustRegionSummary Summary;
+  TrustRegionOptions solver_options;  // ceres::Solver::Options as backend/pose_graph.h:56-68 sets them
   std::map<int, Pose4> poses;
   std::set<int> constant;
   std::vector<RelativePoseConstraint> rel, submap_rel;  // submap_rel: consecutive-submap constraints, reset on every update
@@ -213,12 +213,26 @@ class PoseGraph {
         cost_keep = cost;
         cost = 0.0;
       }
-      for (const RegistrationConstraint* cp : all)
-        if (!cp->cost->BeginNormalEquations(P.at(cp->a).v, P.at(cp->b).v)) throw std::runtime_error("registration constraint: begin failed");
-      for (const RegistrationConstraint* cp : all) {
-        const RegistrationConstraint& c = *cp;
-        double H8[64], b8[8], ck = 0.0;
-        if (!c.cost->FinishNormalEquations(H8, b8, &ck)) throw std::runtime_error("registration constraint: finish failed");
+      // ONE launch for all of this rank's constraints (cox_reg_normal_eq_batch); a single constraint takes the call of its own
+      std::vector<double> H8s(64 * all.size()), b8s(8 * all.size()), cks(all.size(), 0.0);
+      if (all.size() >= 2) {
+        std::vector<const RegistrationCostFunction*> costs;
+        std::vector<double> pr, pd;
+        for (const RegistrationConstraint* cp : all) {
+          costs.push_back(cp->cost);
+          pr.insert(pr.end(), P.at(cp->a).v, P.at(cp->a).v + 4);
+          pd.insert(pd.end(), P.at(cp->b).v, P.at(cp->b).v + 4);
+        }
+        if (!RegistrationCostFunction::NormalEquationsBatch(costs, pr.data(), pd.data(), H8s.data(), b8s.data(), cks.data()))
+          throw std::runtime_error("registration constraints: batched evaluation failed");
+      } else {
+        for (size_t k = 0; k < all.size(); ++k)
+          if (!all[k]->cost->NormalEquations(P.at(all[k]->a).v, P.at(all[k]->b).v, &H8s[64 * k], &b8s[8 * k], &cks[k]))
+            throw std::runtime_error("registration constraint: evaluation failed");
+      }
+      for (size_t k = 0; k < all.size(); ++k) {
+        const RegistrationConstraint& c = *all[k];
+        const double *H8 = &H8s[64 * k], *b8 = &b8s[8 * k];
         double Haa[16], Hab[16], Hbb[16];
         for (int r = 0; r < 4; ++r)
           for (int cc = 0; cc < 4; ++cc) {
@@ -227,7 +241,7 @@ class PoseGraph {
             Hbb[4 * r + cc] = H8[8 * (r + 4) + 4 + cc];
           }
         scatter(c.a, c.b, Haa, Hab, Hbb, b8, b8 + 4);
-        cost += ck;
+        cost += cks[k];
       }
       if (comm) {
         std::vector<double> buf(static_cast<size_t>(n) * n + n + 1);
@@ -268,10 +282,9 @@ class PoseGraph {
     return cost;
   }
 
-  // Levenberg-Marquardt with the Ceres parameter_tolerance test (backend/pose_graph.h:60)
-  Summary optimize(bool exclude_registration = false, int max_iterations = 50, double parameter_tolerance = 3e-3) {
-    std::map<int, Pose4> P = poses;
-    if (!exclude_registration) {  // the sampler's draws of this solve (voxgraph redraws in every Evaluate; one set per solve keeps LM's cost comparisons meaningful)
+  // ceres::Solve(options, &problem, &summary) of backend/pose_graph.h:56-73 (the policy: coxgraph_hip_solver.hpp)
+  Summary optimize(bool exclude_registration = false) {
+    if (!exclude_registration) {  // the sampler's draws of this solve (voxgraph redraws in every Evaluate; one set per solve keeps the cost comparisons of the trust region meaningful)
       ++solve_counter;
       uint64_t k = 0;
       for (auto* list : {&reg, &overlap_reg})
@@ -280,85 +293,31 @@ class PoseGraph {
           if (c.cost && c.sampling_ratio >= 0.0) c.cost->drawSamples(static_cast<uint64_t>(c.sampling_ratio * static_cast<double>(c.cost->num_points())), solve_counter * 1000003ull + k);
         }
     }
-    std::vector<double> g, H, g2, H2;
     std::vector<int> free_ids;
-    double cost = build(P, exclude_registration, &g, &H, &free_ids);
-    Summary S;
-    S.initial_cost = cost;
-    S.evaluations = 1;
-    double lam = 1e-4;
-    const int n = static_cast<int>(g.size());
-    if (n > 0) {
-      for (int it = 1; it <= max_iterations; ++it) {
-        S.iterations = it;
-        std::vector<double> A(H), rhs(n), delta(n);
-        for (int i = 0; i < n; ++i) {
-          A[static_cast<size_t>(i) * n + i] += lam * std::max(H[static_cast<size_t>(i) * n + i], 1e-12);
-          rhs[i] = -g[i];
-        }
-        if (!solve(&A, &rhs, n, &delta)) {
-          lam *= 10.0;
-          continue;
-        }
-        std::map<int, Pose4> trial = P;
-        for (size_t k = 0; k < free_ids.size(); ++k) {
-          Pose4& t = trial[free_ids[k]];
-          for (int c = 0; c < 3; ++c) t.v[c] += delta[4 * k + c];
-          t.v[3] = normalizeAngle(t.v[3] + delta[4 * k + 3]);  // angle local parameterisation
-        }
-        std::vector<int> ids2;
-        const double c2 = build(trial, exclude_registration, &g2, &H2, &ids2);
-        S.evaluations += 1;
-        if (c2 < cost) {
-          double x2 = 0.0, d2 = 0.0;
-          for (int id : free_ids)
-            for (int c = 0; c < 4; ++c) x2 += P[id].v[c] * P[id].v[c];
-          for (double d : delta) d2 += d * d;
-          P = trial;
-          cost = c2;
-          g = g2;
-          H = H2;
-          lam = std::max(lam / 3.0, 1e-12);
-          if (std::sqrt(d2) <= parameter_tolerance * (std::sqrt(x2) + parameter_tolerance)) break;
-        } else {
-          lam *= 4.0;
-          if (lam > 1e12) break;
-        }
-      }
-    }
-    poses = P;
-    S.final_cost = cost;
+    for (const auto& kv : poses)
+      if (!constant.count(kv.first)) free_ids.push_back(kv.first);
+    std::vector<double> x;
+    for (int id : free_ids) x.insert(x.end(), poses[id].v, poses[id].v + 4);
+    auto unpack = [&](const std::vector<double>& xx) {
+      std::map<int, Pose4> P = poses;
+      for (size_t k = 0; k < free_ids.size(); ++k)
+        for (int c = 0; c < 4; ++c) P[free_ids[k]].v[c] = xx[4 * k + c];
+      return P;
+    };
+    auto evaluate = [&](const std::vector<double>& xx, std::vector<double>* g, std::vector<double>* H) {
+      std::vector<int> ids;
+      return build(unpack(xx), exclude_registration, g, H, &ids);
+    };
+    auto plus = [](const std::vector<double>& xx, const std::vector<double>& d) {  // x, y, z plain; yaw: AngleLocalParameterization
+      std::vector<double> y(xx.size());
+      for (size_t i = 0; i < xx.size(); ++i) y[i] = (i % 4 == 3) ? normalizeAngle(xx[i] + d[i]) : xx[i] + d[i];
+      return y;
+    };
+    Summary S = trustRegionMinimize(evaluate, plus, &x, solver_options);
+    poses = unpack(x);
     return S;
   }
 
- private:
-  // Gaussian elimination with partial pivoting; false when singular
-  static bool solve(std::vector<double>* A, std::vector<double>* b, int n, std::vector<double>* x) {
-    std::vector<double>& M = *A;
-    std::vector<double>& r = *b;
-    for (int k = 0; k < n; ++k) {
-      int piv = k;
-      for (int i = k + 1; i < n; ++i)
-        if (std::fabs(M[static_cast<size_t>(i) * n + k]) > std::fabs(M[static_cast<size_t>(piv) * n + k])) piv = i;
-      if (!(std::fabs(M[static_cast<size_t>(piv) * n + k]) > 1e-300)) return false;
-      if (piv != k) {
-        for (int j = 0; j < n; ++j) std::swap(M[static_cast<size_t>(k) * n + j], M[static_cast<size_t>(piv) * n + j]);
-        std::swap(r[k], r[piv]);
-      }
-      for (int i = k + 1; i < n; ++i) {
-        const double f = M[static_cast<size_t>(i) * n + k] / M[static_cast<size_t>(k) * n + k];
-        if (f == 0.0) continue;
-        for (int j = k; j < n; ++j) M[static_cast<size_t>(i) * n + j] -= f * M[static_cast<size_t>(k) * n + j];
-        r[i] -= f * r[k];
-      }
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double s = r[i];
-      for (int j = i + 1; j < n; ++j) s -= M[static_cast<size_t>(i) * n + j] * (*x)[j];
-      (*x)[i] = s / M[static_cast<size_t>(i) * n + i];
-    }
-    return true;
-  }
 };
 
 // The facade coxgraph's server calls (coxgraph/include/coxgraph/server/pose_graph_interface.h:19-108, the voxgraph base

@@ -7,15 +7,151 @@ Host-side mirror of what coxgraph's server drives through voxgraph + Ceres:
   node 0 constant, yaw local parameterisation                   pose_graph_interface.cpp:20-25, backend/node_collection.h:22-24
   solver budget: parameter_tolerance 3e-3                       backend/pose_graph.h:60-64
 
-Ceres is replaced by a small dense Levenberg-Marquardt (the graphs have tens of nodes).  Registration
+Ceres itself is not in the image; its trust-region minimiser is restated here from its published description (Solver::Options
+defaults + the two values coxgraph overrides) on dense normal equations (the graphs have tens of nodes): TrustRegionOptions /
+trust_region_minimize below, line for line the same policy as coxgraph_amd/host/coxgraph_hip_solver.hpp.  Registration
 constraints are evaluated on the GPU in their fused form (cox_reg_normal_eq: H 8x8, b 8, cost); with more
 than one rank they are dealt round-robin and every LM evaluation sums ONE packed buffer of
 (4N)^2 + 4N + 1 doubles with a single all-reduce -- never one call per constraint.
 All ranks then solve the same small system redundantly, so no broadcast is needed.
 """
 import math
+import time
 
 import numpy as np
+
+
+class TrustRegionOptions:
+    """ceres::Solver::Options as coxgraph's server runs it (coxgraph/include/coxgraph/server/backend/pose_graph.h:56-68 sets
+    parameter_tolerance 3e-3, max_solver_time_in_seconds 4, num_threads 4 and SPARSE_SCHUR; everything else is Ceres' default)."""
+    max_num_iterations = 50
+    max_solver_time_in_seconds = 4.0
+    function_tolerance = 1e-6
+    gradient_tolerance = 1e-10
+    parameter_tolerance = 3e-3
+    min_relative_decrease = 1e-3
+    initial_trust_region_radius = 1e4
+    max_trust_region_radius = 1e16
+    min_trust_region_radius = 1e-32
+    min_lm_diagonal = 1e-6
+    max_lm_diagonal = 1e32
+    max_num_consecutive_invalid_steps = 5
+    jacobi_scaling = True
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(type(self), k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+def trust_region_minimize(evaluate, x0, plus, opt=None, clock=time.perf_counter):
+    """Ceres' TrustRegionMinimizer with the LEVENBERG_MARQUARDT strategy (monotonic steps, no inner iterations, no bounds) on the
+    normal equations.  evaluate(x) -> (cost, g = J^T f, H = J^T J); plus(x, delta) = the (local) parameterisation's Plus.
+
+    Per iteration, as Ceres does it:
+      step      D^2 = clamp(diag(H_s), min_lm_diagonal, max_lm_diagonal) / radius;  (H_s + D^2) d_s = -g_s;  d = scale * d_s
+                (_s: Jacobian columns scaled by 1 / (1 + ||column||), the norms taken once at the initial point: jacobi_scaling)
+      validity  model_cost_change = -d_s.(g_s + H_s d_s / 2) must be > 0, else the step is invalid: radius /= 2, and
+                max_num_consecutive_invalid_steps of them in a row fail the solve
+      stop      ||d|| <= parameter_tolerance (||x|| + parameter_tolerance), then |cost change| <= function_tolerance * cost --
+                both BEFORE the step is taken, so x stays where it was
+      accept    rho = cost change / model_cost_change > min_relative_decrease: x <- candidate, stop if max |gradient| <=
+                gradient_tolerance, radius <- min(max_radius, radius / max(1/3, 1 - (2 rho - 1)^3)), decrease factor <- 2
+      reject    radius /= decrease factor, decrease factor *= 2
+      before every iteration: max_num_iterations, max_solver_time_in_seconds, radius <= min_trust_region_radius
+    -> (x, summary)."""
+    opt = opt or TrustRegionOptions()
+    t_start = clock()
+    x = np.array(x0, np.float64)
+    n = x.size
+    cost, g, H = evaluate(x)
+    summary = dict(initial_cost=cost, final_cost=cost, iterations=0, evaluations=1, successful_steps=0, unsuccessful_steps=0, termination="CONVERGENCE",
+                   message="", trace=[])
+
+    def finish(term, msg):
+        summary.update(final_cost=cost, termination=term, message=msg)
+        return x, summary
+    if n == 0:
+        return finish("CONVERGENCE", "no free parameters")
+    g = np.asarray(g, np.float64)
+    H = np.asarray(H, np.float64)
+    scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(H), 0.0))) if opt.jacobi_scaling else np.ones(n)
+
+    def gradient_max_norm(xx, gg):
+        return float(np.max(np.abs(xx - plus(xx, -gg))))
+    gmax = gradient_max_norm(x, g)
+    summary["trace"].append(dict(iteration=0, cost=cost, cost_change=0.0, gradient_max_norm=gmax, step_norm=0.0, relative_decrease=0.0,
+                                 trust_region_radius=opt.initial_trust_region_radius, step_is_valid=False, step_is_successful=False))
+    if gmax <= opt.gradient_tolerance:
+        return finish("CONVERGENCE", "Gradient tolerance reached.")
+    radius, decrease_factor, invalid = opt.initial_trust_region_radius, 2.0, 0
+    x_norm = float(np.linalg.norm(x))
+    iteration = 0
+    while True:
+        if iteration >= opt.max_num_iterations:
+            return finish("NO_CONVERGENCE", "Maximum number of iterations reached.")
+        if clock() - t_start >= opt.max_solver_time_in_seconds:
+            return finish("NO_CONVERGENCE", "Maximum solver time reached.")
+        if radius <= opt.min_trust_region_radius:
+            return finish("CONVERGENCE", "Minimum trust region radius reached.")
+        iteration += 1
+        summary["iterations"] = iteration
+        Hs = H * scale[:, None] * scale[None, :]
+        gs = g * scale
+        D2 = np.clip(np.diag(Hs), opt.min_lm_diagonal, opt.max_lm_diagonal) / radius
+        it = dict(iteration=iteration, cost=cost, cost_change=0.0, gradient_max_norm=gmax, step_norm=0.0, relative_decrease=0.0, trust_region_radius=radius,
+                  step_is_valid=False, step_is_successful=False)
+        summary["trace"].append(it)
+        valid = True
+        try:
+            ds = np.linalg.solve(Hs + np.diag(D2), -gs)
+            valid = bool(np.all(np.isfinite(ds)))
+        except np.linalg.LinAlgError:
+            valid = False
+        model_cost_change = 0.0
+        if valid:
+            model_cost_change = -float(ds @ (gs + 0.5 * (Hs @ ds)))
+            valid = model_cost_change > 0.0
+        if not valid:
+            invalid += 1
+            if invalid >= opt.max_num_consecutive_invalid_steps:
+                return finish("FAILURE", "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.")
+            radius *= 0.5
+            it["trust_region_radius"] = radius
+            continue
+        invalid = 0
+        it["step_is_valid"] = True
+        delta = ds * scale
+        cand = plus(x, delta)
+        c2, g2, H2 = evaluate(cand)
+        summary["evaluations"] += 1
+        step_norm = float(np.linalg.norm(x - cand))
+        it["step_norm"] = step_norm
+        it["cost_change"] = cost - c2
+        if step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance):
+            return finish("CONVERGENCE", "Parameter tolerance reached.")
+        if abs(cost - c2) <= opt.function_tolerance * cost:
+            return finish("CONVERGENCE", "Function tolerance reached.")
+        rho = (cost - c2) / model_cost_change
+        it["relative_decrease"] = rho
+        if rho > opt.min_relative_decrease:
+            x, cost, g, H = cand, c2, np.asarray(g2, np.float64), np.asarray(H2, np.float64)
+            x_norm = float(np.linalg.norm(x))
+            it["step_is_successful"] = True
+            it["cost"] = cost
+            summary["successful_steps"] += 1
+            gmax = gradient_max_norm(x, g)
+            it["gradient_max_norm"] = gmax
+            if gmax <= opt.gradient_tolerance:
+                return finish("CONVERGENCE", "Gradient tolerance reached.")
+            radius = min(opt.max_trust_region_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
+            decrease_factor = 2.0
+        else:
+            summary["unsuccessful_steps"] += 1
+            radius /= decrease_factor
+            decrease_factor *= 2.0
+        it["trust_region_radius"] = radius
 
 
 def normalize_angle(a):
@@ -130,10 +266,15 @@ class PoseGraph:
             H_save, g_save = H, g
             H, g = Hr, gr
             mine = [c for k, c in enumerate(all_reg) if k % world == rank and c is not None]
-            for c in mine:
-                c.begin(poses[c.a], poses[c.b])
-            for c in mine:
-                H8, g8, ck = c.finish()
+            batchable = len(mine) >= 2 and all(c.sample_idx is None and hasattr(type(c.reg), "normal_eq_batch") for c in mine)
+            if batchable:  # ONE launch for this rank's constraints (cox_reg_normal_eq_batch)
+                results = type(mine[0].reg).normal_eq_batch([c.reg for c in mine], [poses[c.a] for c in mine], [poses[c.b] for c in mine])
+            else:          # begin them all, then collect: their kernels overlap
+                for c in mine:
+                    c.begin(poses[c.a], poses[c.b])
+                results = [c.finish() for c in mine]
+            for c, res in zip(mine, results):
+                H8, g8, ck = res[0], res[1], res[2]
                 scatter(c.a, c.b, H8[:4, :4], H8[:4, 4:], H8[4:, 4:], g8[:4], g8[4:])
                 cr += ck
             H, g = H_save, g_save
@@ -156,38 +297,30 @@ class PoseGraph:
             cost += 0.5 * float(r @ r)
         return cost, g, H, free
 
-    # ---- Levenberg-Marquardt ------------------------------------------------------------------------------------
-    def optimize(self, exclude_registration=False, max_iterations=50, parameter_tolerance=3e-3, group=None):
-        poses = {k: v.copy() for k, v in self.poses.items()}
-        cost, g, H, free = self.build(poses, exclude_registration, group)
-        lam, it, n_eval = 1e-4, 0, 1
-        initial = cost
-        if free:
-            for it in range(1, max_iterations + 1):
-                A = H + lam * np.diag(np.maximum(np.diag(H), 1e-12))
-                try:
-                    delta = np.linalg.solve(A, -g)
-                except np.linalg.LinAlgError:
-                    lam *= 10.0
-                    continue
-                trial = {k: v.copy() for k, v in poses.items()}
-                for k, nid in enumerate(free):
-                    trial[nid][:3] += delta[4 * k:4 * k + 3]
-                    trial[nid][3] = normalize_angle(trial[nid][3] + delta[4 * k + 3])  # angle local parameterisation
-                c2, g2, H2, _ = self.build(trial, exclude_registration, group)
-                n_eval += 1
-                if c2 < cost:
-                    x_norm = math.sqrt(sum(float(poses[nid] @ poses[nid]) for nid in free))
-                    poses, cost, g, H = trial, c2, g2, H2
-                    lam = max(lam / 3.0, 1e-12)
-                    if np.linalg.norm(delta) <= parameter_tolerance * (x_norm + parameter_tolerance):  # Ceres parameter_tolerance test
-                        break
-                else:
-                    lam *= 4.0
-                    if lam > 1e12:
-                        break
-        self.poses = poses
-        self.last_summary = dict(initial_cost=initial, final_cost=cost, iterations=it, evaluations=n_eval)
+    # ---- ceres::Solve as coxgraph configures it (backend/pose_graph.h:56-68) ---------------------------------------------
+    def optimize(self, exclude_registration=False, options=None, group=None):
+        opt = options or TrustRegionOptions()
+        idx, free = self._free_index()
+        base = {k: v.copy() for k, v in self.poses.items()}
+
+        def unpack(x):
+            poses = {k: v.copy() for k, v in base.items()}
+            for k, nid in enumerate(free):
+                poses[nid] = np.array(x[4 * k:4 * k + 4], np.float64)
+            return poses
+
+        def evaluate(x):
+            cost, g, H, _ = self.build(unpack(x), exclude_registration, group)
+            return cost, g, H
+
+        def plus(x, delta):  # x, y, z plain; yaw: voxgraph's AngleLocalParameterization (normalised sum)
+            y = np.array(x, np.float64) + delta
+            y[3::4] = [normalize_angle(a) for a in y[3::4]]
+            return y
+        x0 = np.concatenate([self.poses[nid] for nid in free]) if free else np.zeros(0)
+        x, summary = trust_region_minimize(evaluate, x0, plus, opt)
+        self.poses = unpack(x)
+        self.last_summary = summary
         return self.last_summary
 
 

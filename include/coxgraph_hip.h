@@ -323,6 +323,13 @@ int cox_reg_normal_eq(cox_reg_t* reg, const double pose_ref[4], const double pos
  * begin may be outstanding per handle. */
 int cox_reg_normal_eq_begin(cox_reg_t* reg, const double pose_ref[4], const double pose_read[4], const uint32_t* sample_idx, uint64_t n_res);
 int cox_reg_normal_eq_finish(cox_reg_t* reg, double H[64], double b[8], double* cost, uint64_t* n_corr);
+/* All the registration constraints of ONE pose-graph evaluation in ONE launch (Ceres evaluates every residual block of the problem
+ * per iteration, include/coxgraph/server/backend/pose_graph.h:52-73; BASELINE configs[4] has 28 of them): regs[c] with the poses
+ * poses_ref[4c..], poses_read[4c..]; every handle uses its stored sample set (cox_reg_set_samples / cox_reg_draw_samples) or, without
+ * one, all its points in order.  Outputs per constraint as cox_reg_normal_eq: H[64c..], b[8c..], cost[c], n_corr[c] (may be NULL).
+ * All handles on one GPU; bit-identical to n calls of cox_reg_normal_eq.  Synchronous. */
+int cox_reg_normal_eq_batch(cox_reg_t* const* regs, uint64_t n, const double* poses_ref, const double* poses_read, double* H, double* b, double* cost,
+                            uint64_t* n_corr);
 /* Keep a set of sample indices on the GPU: later calls that pass sample_idx = NULL with this n_res use them (no 4*n_res
  * byte upload per evaluation).  sample_idx = NULL here drops the stored set (NULL then means "all points in order" again). */
 int cox_reg_set_samples(cox_reg_t* reg, const uint32_t* sample_idx, uint64_t n_res);

@@ -399,6 +399,19 @@ int coxo_reg_normal_eq_finish(coxo_reg* reg, double H[64], double b[8], double* 
   if (n_corr) *n_corr = reg->n_corr;
   return COX_OK;
 }
+// all constraints of one pose-graph evaluation (cox_reg_normal_eq_batch): the oracle takes them one after the other
+int coxo_reg_normal_eq_batch(coxo_reg* const* regs, uint64_t n, const double* poses_ref, const double* poses_read, double* H, double* b, double* cost,
+                             uint64_t* n_corr) {
+  if (!regs || !n || !poses_ref || !poses_read || !H || !b || !cost) return COX_ERR_INVALID_ARG;
+  for (uint64_t c = 0; c < n; ++c) {
+    coxo_reg* reg = regs[c];
+    if (!reg || reg->pending) return COX_ERR_INVALID_ARG;
+    const uint64_t nr = reg->has_stored ? reg->stored.size() : reg->ref->pts.size();
+    const int rc = regRun(reg, poses_ref + 4 * c, poses_read + 4 * c, nullptr, nr, nullptr, nullptr, nullptr, H + 64 * c, b + 8 * c, cost + c, n_corr ? n_corr + c : nullptr);
+    if (rc != COX_OK) return rc;
+  }
+  return COX_OK;
+}
 int coxo_reg_set_samples(coxo_reg* reg, const uint32_t* sample_idx, uint64_t n_res) {
   if (!reg || reg->pending) return COX_ERR_INVALID_ARG;
   reg->has_stored = sample_idx != nullptr;

@@ -178,7 +178,48 @@ static int serverFlow() {
   return 0;
 }
 
+// the trust-region minimiser on two problems whose iteration traces are derived by hand in tests/test_host_logic.py
+static int solverKats() {
+  {  // r = 2 x - 6 from x = 0
+    std::vector<double> x{0.0};
+    auto ev = [](const std::vector<double>& xx, std::vector<double>* g, std::vector<double>* H) {
+      const double r = 2.0 * xx[0] - 6.0;
+      g->assign(1, 2.0 * r);
+      H->assign(1, 4.0);
+      return 0.5 * r * r;
+    };
+    auto plus = [](const std::vector<double>& xx, const std::vector<double>& d) { return std::vector<double>{xx[0] + d[0]}; };
+    const TrustRegionSummary S = trustRegionMinimize(ev, plus, &x);
+    std::printf("linear %.17g %d %s|", x[0], S.iterations, S.message.c_str());
+    for (const auto& it : S.trace) std::printf(" %d %.17g %.17g %.17g %.17g", it.iteration, it.cost, it.step_norm, it.relative_decrease, it.trust_region_radius);
+    std::printf("\n");
+    TrustRegionOptions o;
+    o.parameter_tolerance = 0.0;
+    x[0] = 0.0;
+    const TrustRegionSummary S2 = trustRegionMinimize(ev, plus, &x, o);
+    std::printf("linear_gradient %.17g %d %s\n", x[0], S2.iterations, S2.message.c_str());
+  }
+  {  // r = x^3 - 1 from x = 0.1: six rejected steps before the first accepted one
+    std::vector<double> x{0.1};
+    auto ev = [](const std::vector<double>& xx, std::vector<double>* g, std::vector<double>* H) {
+      const double r = xx[0] * xx[0] * xx[0] - 1.0, J = 3.0 * xx[0] * xx[0];
+      g->assign(1, J * r);
+      H->assign(1, J * J);
+      return 0.5 * r * r;
+    };
+    auto plus = [](const std::vector<double>& xx, const std::vector<double>& d) { return std::vector<double>{xx[0] + d[0]}; };
+    TrustRegionOptions o;
+    o.parameter_tolerance = 1e-12;
+    const TrustRegionSummary S = trustRegionMinimize(ev, plus, &x, o);
+    std::printf("cubic %.17g %d %d %d %s|", x[0], S.iterations, S.successful_steps, S.unsuccessful_steps, S.message.c_str());
+    for (const auto& it : S.trace) std::printf(" %d %d %.17g %.17g", it.iteration, it.step_is_successful ? 1 : 0, it.cost, it.trust_region_radius);
+    std::printf("\n");
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::strcmp(argv[1], "lm") == 0) return solverKats();
   // square-root information: S^T S == information, also for a semi-definite matrix (eigen branch)
   const double semi[16] = {4, 2, 0, 0, 2, 1, 0, 0, 0, 0, 9, 0, 0, 0, 0, 0};
   double S[16];

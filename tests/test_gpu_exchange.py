@@ -182,3 +182,50 @@ def test_rccl_paths_on_one_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, os.path.join(here, "nccl_single_rank.py"), str(port)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])  # (RCCL prints a banner first)
+
+
+def test_batched_evaluation_of_all_constraints_in_one_launch(hip, oracle, client_submaps):
+    """cox_reg_normal_eq_batch (round 3): the six constraints (a, b), a != b, of one pose-graph evaluation in ONE launch -- each
+    with its own poses, its own drawn samples (different sizes) -- are, bit for bit, what six calls of cox_reg_normal_eq give,
+    equal the oracle's to 1e-6, and PoseGraph.build takes the batched path and returns the same cost / gradient / matrix."""
+    from coxgraph_amd.posegraph import PoseGraph, RegistrationConstraint
+    trunc = 3 * VOXEL
+    lh, lo = client_submaps["hip"], client_submaps["oracle"]
+    ref_h = [RegPoints.from_layer(hip, l, 1.0, trunc) for l in lh]
+    ref_o = [RegPoints.from_layer(oracle, l, 1.0, trunc) for l in lo]
+    pairs = [(a, b) for a in range(N_CLIENTS) for b in range(N_CLIENTS) if a != b]
+    regs_h, regs_o, poses_ref, poses_read = [], [], [], []
+    rng = np.random.default_rng(11)
+    for k, (a, b) in enumerate(pairs):
+        gh, go = Registration(hip, ref_h[a], lh[b], 0.0), Registration(oracle, ref_o[a], lo[b], 0.0)
+        if k == 2:
+            pass  # no stored samples: every point once
+        else:
+            gh.draw_samples(int((0.1 + 0.05 * k) * ref_h[a].n), 500 + k)
+            go.set_samples(gh.get_samples())
+        regs_h.append(gh)
+        regs_o.append(go)
+        poses_ref.append(rng.normal(scale=0.01, size=4))
+        poses_read.append(np.array([0.05, -0.03, 0.02, np.radians(1.0)]) + rng.normal(scale=0.01, size=4))
+    batch = Registration.normal_eq_batch(regs_h, poses_ref, poses_read)
+    for k, (gh, go) in enumerate(zip(regs_h, regs_o)):
+        Hs, bs, cs, ns = gh.normal_eq(poses_ref[k], poses_read[k])
+        Hb, bb, cb, nb_ = batch[k]
+        assert np.array_equal(Hs, Hb) and np.array_equal(bs, bb) and cs == cb and ns == nb_, k
+        Ho, bo, co, no = go.normal_eq(poses_ref[k], poses_read[k])
+        assert ns == no and ns > 100
+        assert np.max(np.abs(Hb - Ho)) <= 1e-6 * max(1.0, float(np.max(np.abs(Ho))))
+        assert np.max(np.abs(bb - bo)) <= 1e-6 * max(1.0, float(np.max(np.abs(bo)))) and abs(cb - co) <= 1e-6 * max(1.0, co)
+    # through the pose graph: batched (sample_idx None on every constraint) == one call per constraint
+    def graph(regs, force_single):
+        pg = PoseGraph()
+        for c in range(N_CLIENTS):
+            pg.add_node(c, [0.01 * c, -0.005 * c, 0.002 * c, 0.001 * c], constant=(c == 0))
+        for (a, b), g in zip(pairs, regs):
+            pg.reg.append(RegistrationConstraint(a, b, g, sample_idx=(g.get_samples() if force_single and g.get_samples().size else None)))
+        return pg.build({k: v.copy() for k, v in pg.poses.items()})
+    cost_b, g_b, H_b, _ = graph(regs_h, False)
+    cost_s, g_s, H_s, _ = graph([r for r in regs_h], True)
+    assert np.allclose(H_b, H_s, rtol=1e-12, atol=0) and np.allclose(g_b, g_s, rtol=1e-12, atol=1e-12) and abs(cost_b - cost_s) <= 1e-12 * max(1.0, cost_s)
+    cost_o, g_o, H_o, _ = graph(regs_o, False)
+    assert np.allclose(H_b, H_o, rtol=1e-6, atol=1e-6 * np.max(np.abs(H_o))) and abs(cost_b - cost_o) <= 1e-6 * max(1.0, cost_o)

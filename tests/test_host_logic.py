@@ -44,6 +44,86 @@ def test_relative_pose_cost_known_answers_and_jacobian():
         assert np.allclose((c3.evaluate(pa, pb + e)[0] - c3.evaluate(pa, pb - e)[0]) / (2 * h), Jb[:, k], atol=1e-5)
 
 
+def _linear(x):
+    r = 2.0 * x[0] - 6.0
+    return 0.5 * r * r, np.array([2.0 * r]), np.array([[4.0]])
+
+
+def _cubic(x):
+    r, J = x[0] ** 3 - 1.0, 3.0 * x[0] ** 2
+    return 0.5 * r * r, np.array([J * r]), np.array([[J * J]])
+
+
+def test_trust_region_trace_derived_by_hand():
+    """Ceres' policy (backend/pose_graph.h:56-68 + Solver::Options defaults) on r = 2x - 6 from x = 0, by hand: with Jacobi scaling the
+    LM step of a one-parameter linear problem is the Gauss-Newton step times R / (R + 1) (R = trust-region radius, 1e4 at first), the
+    model is exact (rho = 1), so the radius triples; the second step, 3e-4, is below parameter_tolerance * (|x| + parameter_tolerance)
+    = 3e-3 * 3.0027 and the solve ends BEFORE taking it."""
+    from coxgraph_amd.posegraph import trust_region_minimize, TrustRegionOptions
+    x, s = trust_region_minimize(_linear, [0.0], lambda x, d: x + d)
+    x1 = 3.0 * 1e4 / (1e4 + 1.0)
+    assert s["termination"] == "CONVERGENCE" and s["message"] == "Parameter tolerance reached." and s["iterations"] == 2 and s["evaluations"] == 3
+    assert abs(x[0] - x1) < 1e-15
+    t = s["trace"]
+    assert t[0]["cost"] == 18.0 and t[0]["trust_region_radius"] == 1e4
+    assert abs(t[1]["step_norm"] - x1) < 1e-15 and abs(t[1]["relative_decrease"] - 1.0) < 1e-9 and t[1]["trust_region_radius"] == 3e4 and t[1]["step_is_successful"]
+    assert abs(t[1]["cost"] - 0.5 * (6.0 / 10001.0) ** 2) < 1e-18
+    assert abs(t[2]["step_norm"] - (3.0 - x1) * 3e4 / (3e4 + 1.0)) < 1e-15 and not t[2]["step_is_successful"]
+    # without the parameter test the residual shrinks by (R + 1) per step, R = 1e4, 3e4, 9e4: |gradient| = 2 |r| = 4.4e-13 <= 1e-10 after three
+    x, s = trust_region_minimize(_linear, [0.0], lambda x, d: x + d, TrustRegionOptions(parameter_tolerance=0.0))
+    assert s["message"] == "Gradient tolerance reached." and s["iterations"] == 3
+    assert abs((2.0 * x[0] - 6.0) - (-6.0 / 10001.0 / 30001.0 / 90001.0)) < 2e-15  # (-2.2e-13, to the rounding of 2x - 6 at x = 3)
+    # a start at the optimum ends in iteration 0
+    x, s = trust_region_minimize(_linear, [3.0], lambda x, d: x + d)
+    assert s["iterations"] == 0 and s["message"] == "Gradient tolerance reached."
+    # budget checks come before every iteration
+    x, s = trust_region_minimize(_linear, [0.0], lambda x, d: x + d, TrustRegionOptions(max_num_iterations=1, parameter_tolerance=0.0))
+    assert s["termination"] == "NO_CONVERGENCE" and s["iterations"] == 1
+    x, s = trust_region_minimize(_linear, [0.0], lambda x, d: x + d, TrustRegionOptions(max_solver_time_in_seconds=0.0))
+    assert s["termination"] == "NO_CONVERGENCE" and s["message"] == "Maximum solver time reached." and s["iterations"] == 0
+
+
+def test_trust_region_rejected_steps_shrink_the_radius_as_ceres_does():
+    """r = x^3 - 1 from x = 0.1: the Jacobian is tiny there, the first steps overshoot by orders of magnitude and are rejected
+    (rho < min_relative_decrease); every rejection divides the radius by a factor that doubles (2, 4, 8, ...), an accepted step
+    resets the factor -- radius after k rejections in a row = 1e4 / 2^(k (k + 1) / 2), by hand."""
+    from coxgraph_amd.posegraph import trust_region_minimize, TrustRegionOptions
+    x, s = trust_region_minimize(_cubic, [0.1], lambda x, d: x + d, TrustRegionOptions(parameter_tolerance=1e-12))
+    t = s["trace"]
+    k = 0
+    while not t[k + 1]["step_is_successful"]:
+        k += 1
+        assert t[k]["trust_region_radius"] == 1e4 / 2.0 ** (k * (k + 1) // 2), (k, t[k])
+    assert k >= 5 and s["unsuccessful_steps"] >= k
+    costs = [it["cost"] for it in t]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))  # monotonic steps only
+    assert abs(x[0] - 1.0) < 1e-6 and s["termination"] == "CONVERGENCE"
+
+
+def test_cpp_trust_region_minimiser_agrees_with_the_python_one(hip, tmp_path):
+    from coxgraph_amd.posegraph import trust_region_minimize, TrustRegionOptions
+    out = subprocess.run([_build_posegraph_smoke(hip, tmp_path), "lm"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = {l.split()[0]: l for l in out.stdout.strip().splitlines()}
+    head, trace = lines["linear"].split("|")
+    x, s = trust_region_minimize(_linear, [0.0], lambda x, d: x + d)
+    assert float(head.split()[1]) == x[0] and int(head.split()[2]) == s["iterations"] and "Parameter tolerance reached." in head
+    vals = [float(v) for v in trace.split()]
+    for k, it in enumerate(s["trace"]):
+        got = vals[5 * k:5 * k + 5]
+        want = [it["iteration"], it["cost"], it["step_norm"], it["relative_decrease"], it["trust_region_radius"]]
+        assert np.allclose(got, want, rtol=1e-14, atol=0), (k, got, want)
+    assert "Gradient tolerance reached." in lines["linear_gradient"] and int(lines["linear_gradient"].split()[2]) == 3
+    head, trace = lines["cubic"].split("|")
+    x, s = trust_region_minimize(_cubic, [0.1], lambda x, d: x + d, TrustRegionOptions(parameter_tolerance=1e-12))
+    h = head.split()
+    assert abs(float(h[1]) - x[0]) < 1e-12 and (int(h[2]), int(h[3]), int(h[4])) == (s["iterations"], s["successful_steps"], s["unsuccessful_steps"])
+    vals = [float(v) for v in trace.split()]
+    for k, it in enumerate(s["trace"]):
+        assert (int(vals[4 * k]), int(vals[4 * k + 1])) == (it["iteration"], int(it["step_is_successful"]))
+        assert np.isclose(vals[4 * k + 2], it["cost"], rtol=1e-7, atol=1e-18) and np.isclose(vals[4 * k + 3], it["trust_region_radius"], rtol=1e-12)
+
+
 def test_loop_closure_chain_optimises_to_consistent_poses():
     g = PoseGraphInterface()
     truth = {0: np.array([0.0, 0, 0, 0]), 1: np.array([1.0, 0.5, 0.1, 0.3]), 2: np.array([2.0, -0.5, 0.2, -0.2])}
@@ -60,10 +140,18 @@ def test_loop_closure_chain_optimises_to_consistent_poses():
         g.addLoopClosureMeasurement(a, b, rel(a, b))
     first, second = g.optimize(enable_registration=False)
     poses = g.getPoseMap()
+    # coxgraph's parameter_tolerance is 3e-3 (backend/pose_graph.h:60): Ceres stops as soon as a step is that small relative to |x|,
+    # WITHOUT taking it -- the poses agree with the truth to a fraction of that, not to rounding
+    assert "Parameter tolerance reached." in (first["message"], second["message"])
     for k in truth:
-        assert np.allclose(poses[k], truth[k], atol=1e-6), (k, poses[k])
+        assert np.allclose(poses[k], truth[k], atol=1e-3), (k, poses[k])
     assert np.array_equal(poses[0], truth[0])  # submap 0 is constant (pose_graph_interface.cpp:20-25)
-    assert second["final_cost"] < 1e-12
+    assert second["final_cost"] < 1e-4
+    # with Ceres' own default (1e-8) the same graph converges to rounding
+    from coxgraph_amd.posegraph import TrustRegionOptions
+    g.pose_graph.optimize(exclude_registration=True, options=TrustRegionOptions(parameter_tolerance=1e-8, function_tolerance=0.0))
+    for k in truth:
+        assert np.allclose(g.getPoseMap()[k], truth[k], atol=1e-6), (k, g.getPoseMap()[k])
 
 
 def plane_layer(eng, voxel=0.1, a=-1.0, b=(1.0, 0.0, 0.0), blocks=None):
