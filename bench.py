@@ -147,7 +147,12 @@ def main():
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)  # one rank per GPU; a rehearsal on a smaller box shares devices
     torch.cuda.set_device(dev_index)
-    backend = os.environ.get("COX_DIST_BACKEND", "nccl")  # "gloo" to rehearse N > 1 on a single-GPU box
+    # "gloo" to rehearse N > 1 on a single-GPU box; "rccl-capi": rendezvous over gloo, the two collectives of the server leg through the
+    # engine's own cox_comm_* (RCCL behind the C ABI: what the C++ host uses) instead of torch.distributed
+    backend = os.environ.get("COX_DIST_BACKEND", "nccl")
+    capi_comm = backend == "rccl-capi"
+    if capi_comm:
+        backend = "gloo"
     if world > 1:
         import datetime
         tmo = datetime.timedelta(seconds=180)  # a rank that dies must not leave the others waiting for the default 10 min
@@ -554,9 +559,24 @@ def main():
         pts_t[:npts].copy_(torch.from_numpy(ref.download()).cuda())  # preparation, not part of the timed exchange
         torch.cuda.synchronize()
         dist.barrier()
+        comm = None
+        if capi_comm:
+            from coxgraph_amd.capi import Comm
+            ids = [Comm.unique_id(eng) if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = Comm(eng, local_rank, rank, world, ids[0])
+            dist.barrier()
         # the exchange: one all-gather of (block indices, voxel words, point sets); device to device over xGMI with RCCL
         t0 = time.perf_counter()
-        if backend == "nccl":
+        if comm is not None:
+            g_idx = torch.empty((world, max_nb, 3), dtype=torch.int32, device="cuda")
+            g_vox = torch.empty((world, max_nb, 4096, 3), dtype=torch.int32, device="cuda")
+            g_pts = torch.empty((world, max_np, 5), dtype=torch.float32, device="cuda")
+            cur = torch.cuda.current_stream().cuda_stream
+            comm.allgather_dev(idx_t.data_ptr(), g_idx.data_ptr(), idx_t.numel() * 4, cur)
+            comm.allgather_dev(vox_t.data_ptr(), g_vox.data_ptr(), vox_t.numel() * 4, cur)
+            comm.allgather_dev(pts_t.data_ptr(), g_pts.data_ptr(), pts_t.numel() * 4, cur)
+        elif backend == "nccl":
             g_idx = torch.empty((world, max_nb, 3), dtype=torch.int32, device="cuda")
             g_vox = torch.empty((world, max_nb, 4096, 3), dtype=torch.int32, device="cuda")
             g_pts = torch.empty((world, max_np, 5), dtype=torch.float32, device="cuda")
@@ -597,12 +617,13 @@ def main():
             n_corr_total += gab.normal_eq(pg.poses[a], pg.poses[b])[3]
             pg.reg.append(RegistrationConstraint(a, b, gab))
         poses = {k: v.copy() for k, v in pg.poses.items()}
-        pg.build(poses, group=dist.group.WORLD)
+        red = dict(comm=comm) if comm is not None else dict(group=dist.group.WORLD)
+        pg.build(poses, **red)
         dist.barrier()
         n_eval = max(4, args.reg_iters // 10)
         t4 = time.perf_counter()
         for _ in range(n_eval):
-            cost, _, _, _ = pg.build(poses, group=dist.group.WORLD)
+            cost, _, _, _ = pg.build(poses, **red)
         torch.cuda.synchronize()
         dist.barrier()
         dt4 = time.perf_counter() - t4
@@ -615,7 +636,8 @@ def main():
                     "correspondences_over_all_constraints": int(tt[1].item()),
                     "submap_exchange_ms": dt_x * 1e3, "submap_exchange_GBps": recv_bytes / dt_x / 1e9, "submap_exchange_bytes_received_per_rank": recv_bytes,
                     "submap_blocks": [s[0] for s in all_sizes], "isosurface_points": [s[1] for s in all_sizes],
-                    "all_reduce_doubles": (4 * (world - 1)) ** 2 + 4 * (world - 1) + 1, "backend": "rccl" if backend == "nccl" else backend, "cost": cost}
+                    "all_reduce_doubles": (4 * (world - 1)) ** 2 + 4 * (world - 1) + 2,
+                    "backend": "rccl through cox_comm_* (C ABI)" if comm is not None else ("rccl through torch.distributed" if backend == "nccl" else backend), "cost": cost}
 
     # ---- CPU baseline on rank 0, N = 1 only ---------------------------------------------------------------
     cpu = None

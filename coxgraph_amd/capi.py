@@ -513,6 +513,45 @@ class Registration:
         return [(H[c], b[c], float(cost[c]), int(nc[c])) for c in range(n)]
 
 
+class Comm:
+    """cox_comm_t: RCCL behind the C ABI (one rank = one process = one GPU) -- the collectives the C++ host uses."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id(eng):
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        eng.check(eng.fn("comm_unique_id")(buf), "comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, eng, device, rank, world, unique_id):
+        self.eng = eng
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * Comm.ID_BYTES).from_buffer_copy(unique_id)
+        eng.check(eng.fn("comm_init_rank")(C.c_int(device), C.c_int(rank), C.c_int(world), buf, C.byref(self.h)), "comm_init_rank")
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self.h:
+            self.eng.fn("comm_destroy", None)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allreduce_f64(self, buf):
+        """in-place sum over the ranks of a float64 numpy array (host in, host out)"""
+        a = np.ascontiguousarray(buf, np.float64)
+        self.eng.check(self.eng.fn("comm_allreduce_f64")(self.h, _fp(a), C.c_uint64(a.size)), "comm_allreduce_f64")
+        return a
+
+    def allgather_dev(self, send_ptr, recv_ptr, bytes_per_rank, producer_stream=0):
+        self.eng.check(self.eng.fn("comm_allgather_dev_on")(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_uint64(bytes_per_rank),
+                                                            C.c_void_p(producer_stream or 0)), "comm_allgather_dev_on")
+
+
 class MeshMsgStruct(C.Structure):
     """cox_mesh_msg."""
     _fields_ = [

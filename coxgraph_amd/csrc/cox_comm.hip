@@ -61,6 +61,7 @@ struct cox_comm {
   hipStream_t stream = nullptr;
   double* d_buf = nullptr;
   uint64_t cap = 0;
+  hipEvent_t ev = nullptr;  // producer stream -> collective stream
 };
 
 #define COX_NCCL(call)                                                                                                                 \
@@ -68,7 +69,7 @@ struct cox_comm {
     ncclResult_t r_ = (call);                                                                                                          \
     if (r_ != ncclSuccess) {                                                                                                           \
       fprintf(stderr, "[coxgraph_hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #call, rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); \
-      return COX_ERR_NO_DEVICE;                                                                                                        \
+      return COX_ERR_COMM;                                                                                                             \
     }                                                                                                                                  \
   } while (0)
 
@@ -107,8 +108,9 @@ int cox_comm_init_rank(int device, int rank, int world, const uint8_t id[COX_COM
     fprintf(stderr, "[coxgraph_hip] ncclCommInitRank -> %s\n", rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
     (void)hipStreamDestroy(C->stream);
     delete C;
-    return COX_ERR_NO_DEVICE;
+    return COX_ERR_COMM;
   }
+  if (hipEventCreateWithFlags(&C->ev, hipEventDisableTiming) != hipSuccess) C->ev = nullptr;
   *out = C;
   return COX_OK;
 }
@@ -119,6 +121,7 @@ void cox_comm_destroy(cox_comm_t* C) {
   if (C->stream) (void)hipStreamSynchronize(C->stream);
   if (C->comm && rccl().ok) (void)rccl().CommDestroy(C->comm);
   if (C->d_buf) (void)hipFree(C->d_buf);
+  if (C->ev) (void)hipEventDestroy(C->ev);
   if (C->stream) (void)hipStreamDestroy(C->stream);
   delete C;
 }
@@ -149,15 +152,27 @@ int cox_comm_allreduce_f64(cox_comm_t* C, double* buf, uint64_t n) {
   return COX_OK;
 }
 
-int cox_comm_allgather_dev(cox_comm_t* C, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
+// producer_stream: the hipStream_t (as void*) whatever wrote send_dev was enqueued on (NULL = the legacy default stream); the
+// collective waits for that stream by an event, not for the whole device
+int cox_comm_allgather_dev_on(cox_comm_t* C, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, void* producer_stream) {
   COX_ENTRY();
   if (!C || (bytes_per_rank && (!send_dev || !recv_dev))) return COX_ERR_INVALID_ARG;
   if (bytes_per_rank == 0) return COX_OK;
   COX_HIP(hipSetDevice(C->device));
-  COX_HIP(hipDeviceSynchronize());  // whatever produced send_dev is done
+  if (C->ev) {
+    COX_HIP(hipEventRecord(C->ev, static_cast<hipStream_t>(producer_stream)));
+    COX_HIP(hipStreamWaitEvent(C->stream, C->ev, 0));
+  } else {
+    COX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(producer_stream)));
+  }
   COX_NCCL(rccl().AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, C->comm, C->stream));
   COX_HIP(hipStreamSynchronize(C->stream));
   return COX_OK;
+}
+// the engine's own exports (cox_layer_export_dev, cox_regpoints_data_dev) are complete when they return and torch tensors are
+// written on torch's current stream: without a stream to name, the legacy default stream orders behind every blocking stream
+int cox_comm_allgather_dev(cox_comm_t* C, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
+  return cox_comm_allgather_dev_on(C, send_dev, recv_dev, bytes_per_rank, nullptr);
 }
 
 }  // extern "C"

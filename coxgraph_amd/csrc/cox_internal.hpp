@@ -83,7 +83,9 @@ struct cox_regpoints {
 // hipGetLastError() is a per-thread sticky slot shared with every other HIP user in the process
 // (PyTorch probes peers / devices during its lazy init and may leave a benign error behind).  Every
 // entry point clears it first so that the check after our own launches only sees our own errors.
+extern "C" bool cox_internal_hip_touched;  // cox_layer.hip: the library has reached the HIP runtime (cox_runtime_prepare comes too late after that)
 static inline void cox_clear_stale_hip_error(const char* where) {
+  cox_internal_hip_touched = true;
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     static const bool verbose = std::getenv("COX_DEBUG") != nullptr;

@@ -74,18 +74,21 @@ const char* cox_status_string(int s) {
     case COX_ERR_UNSUPPORTED: return "COX_ERR_UNSUPPORTED";
     case COX_ERR_BUFFER_TOO_SMALL: return "COX_ERR_BUFFER_TOO_SMALL";
     case COX_ERR_INTERNAL: return "COX_ERR_INTERNAL";
+    case COX_ERR_COMM: return "COX_ERR_COMM";
   }
   return "COX_ERR_?";
 }
 
-// Four stage streams per integrator: ask the runtime for more hardware queues than its default of 4 before it starts, if
-// nobody has chosen a number (stages that share a queue run back to back: 6.1 k instead of 7.5 k frames/s at 5 cm).  Runs
-// when the library is loaded; without effect when the HIP runtime of the process is already up.
-namespace {
-struct QueueHint {
-  QueueHint() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-} g_queue_hint;
-}  // namespace
+// Four stage streams per integrator: the host asks the runtime for more hardware queues than its default of 4 BEFORE the runtime
+// starts (stages that share a queue run back to back: 6.1 k instead of 7.5 k frames/s at 5 cm).  Explicit, not a side effect of
+// loading the library (a static constructor calling setenv races with getenv in the other threads of a host such as a ROS node
+// that dlopens the engine, and silently changes the queue count of every other HIP user in the process).
+bool cox_internal_hip_touched = false;  // set by the first entry point of this library that reaches the HIP runtime
+int cox_runtime_prepare(void) {
+  if (cox_internal_hip_touched) return 0;
+  if (std::getenv("GPU_MAX_HW_QUEUES")) return 0;  // the host's own choice stands
+  return setenv("GPU_MAX_HW_QUEUES", "16", 0) == 0 ? 1 : 0;
+}
 
 int cox_device_count(void) {
   COX_ENTRY();

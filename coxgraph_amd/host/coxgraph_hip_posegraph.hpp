@@ -18,6 +18,8 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include <cstdio>
@@ -213,45 +215,60 @@ class PoseGraph {
         cost_keep = cost;
         cost = 0.0;
       }
-      // ONE launch for all of this rank's constraints (cox_reg_normal_eq_batch); a single constraint takes the call of its own
-      std::vector<double> H8s(64 * all.size()), b8s(8 * all.size()), cks(all.size(), 0.0);
-      if (all.size() >= 2) {
-        std::vector<const RegistrationCostFunction*> costs;
-        std::vector<double> pr, pd;
-        for (const RegistrationConstraint* cp : all) {
-          costs.push_back(cp->cost);
-          pr.insert(pr.end(), P.at(cp->a).v, P.at(cp->a).v + 4);
-          pd.insert(pd.end(), P.at(cp->b).v, P.at(cp->b).v + 4);
-        }
-        if (!RegistrationCostFunction::NormalEquationsBatch(costs, pr.data(), pd.data(), H8s.data(), b8s.data(), cks.data()))
-          throw std::runtime_error("registration constraints: batched evaluation failed");
-      } else {
-        for (size_t k = 0; k < all.size(); ++k)
-          if (!all[k]->cost->NormalEquations(P.at(all[k]->a).v, P.at(all[k]->b).v, &H8s[64 * k], &b8s[8 * k], &cks[k]))
-            throw std::runtime_error("registration constraint: evaluation failed");
-      }
-      for (size_t k = 0; k < all.size(); ++k) {
-        const RegistrationConstraint& c = *all[k];
-        const double *H8 = &H8s[64 * k], *b8 = &b8s[8 * k];
-        double Haa[16], Hab[16], Hbb[16];
-        for (int r = 0; r < 4; ++r)
-          for (int cc = 0; cc < 4; ++cc) {
-            Haa[4 * r + cc] = H8[8 * r + cc];
-            Hab[4 * r + cc] = H8[8 * r + 4 + cc];
-            Hbb[4 * r + cc] = H8[8 * (r + 4) + 4 + cc];
+      // A rank whose evaluation fails must still take part in the all-reduce -- RCCL has no timeout, the other ranks would wait in
+      // ncclAllReduce for ever: it contributes zeros and one in the buffer's extra "failed ranks" word, and every rank throws.
+      std::string local_error;
+      try {
+        // ONE launch for all of this rank's constraints (cox_reg_normal_eq_batch); a single constraint takes the call of its own
+        std::vector<double> H8s(64 * all.size()), b8s(8 * all.size()), cks(all.size(), 0.0);
+        if (all.size() >= 2) {
+          std::vector<const RegistrationCostFunction*> costs;
+          std::vector<double> pr, pd;
+          for (const RegistrationConstraint* cp : all) {
+            costs.push_back(cp->cost);
+            pr.insert(pr.end(), P.at(cp->a).v, P.at(cp->a).v + 4);
+            pd.insert(pd.end(), P.at(cp->b).v, P.at(cp->b).v + 4);
           }
-        scatter(c.a, c.b, Haa, Hab, Hbb, b8, b8 + 4);
-        cost += cks[k];
+          if (!RegistrationCostFunction::NormalEquationsBatch(costs, pr.data(), pd.data(), H8s.data(), b8s.data(), cks.data()))
+            throw std::runtime_error("registration constraints: batched evaluation failed");
+        } else {
+          for (size_t k = 0; k < all.size(); ++k)
+            if (!all[k]->cost->NormalEquations(P.at(all[k]->a).v, P.at(all[k]->b).v, &H8s[64 * k], &b8s[8 * k], &cks[k]))
+              throw std::runtime_error("registration constraint: evaluation failed");
+        }
+        for (size_t k = 0; k < all.size(); ++k) {
+          const RegistrationConstraint& c = *all[k];
+          const double *H8 = &H8s[64 * k], *b8 = &b8s[8 * k];
+          double Haa[16], Hab[16], Hbb[16];
+          for (int r = 0; r < 4; ++r)
+            for (int cc = 0; cc < 4; ++cc) {
+              Haa[4 * r + cc] = H8[8 * r + cc];
+              Hab[4 * r + cc] = H8[8 * r + 4 + cc];
+              Hbb[4 * r + cc] = H8[8 * (r + 4) + 4 + cc];
+            }
+          scatter(c.a, c.b, Haa, Hab, Hbb, b8, b8 + 4);
+          cost += cks[k];
+        }
+      } catch (const std::exception& e) {
+        if (!comm) throw;
+        local_error = e.what();
+        std::fill(g->begin(), g->end(), 0.0);
+        std::fill(H->begin(), H->end(), 0.0);
+        cost = 0.0;
       }
       if (comm) {
-        std::vector<double> buf(static_cast<size_t>(n) * n + n + 1);
+        std::vector<double> buf(static_cast<size_t>(n) * n + n + 2);
         std::copy(H->begin(), H->end(), buf.begin());
         std::copy(g->begin(), g->end(), buf.begin() + static_cast<size_t>(n) * n);
-        buf.back() = cost;
+        buf[static_cast<size_t>(n) * n + n] = cost;
+        buf.back() = local_error.empty() ? 0.0 : 1.0;
         check(cox_comm_allreduce_f64(comm, buf.data(), buf.size()), "all-reduce of the normal equations");
+        if (buf.back() != 0.0)
+          throw std::runtime_error("registration constraints: evaluation failed on " + std::to_string(static_cast<int>(buf.back())) + " rank(s)" +
+                                   (local_error.empty() ? std::string() : ": " + local_error));
         for (size_t i = 0; i < H->size(); ++i) (*H)[i] = H_keep[i] + buf[i];
         for (int i = 0; i < n; ++i) (*g)[i] = g_keep[i] + buf[static_cast<size_t>(n) * n + i];
-        cost = cost_keep + buf.back();
+        cost = cost_keep + buf[static_cast<size_t>(n) * n + n];
       }
     }
     for (const auto* list : {&rel, &submap_rel})

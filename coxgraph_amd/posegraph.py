@@ -234,7 +234,7 @@ class PoseGraph:
         return {nid: k for k, nid in enumerate(free)}, free
 
     # ---- one evaluation of the whole problem: cost, gradient, Gauss-Newton matrix ------------------------------
-    def build(self, poses, exclude_registration=False, group=None):
+    def build(self, poses, exclude_registration=False, group=None, comm=None):
         idx, free = self._free_index()
         n = 4 * len(free)
         H = np.zeros((n, n))
@@ -257,7 +257,9 @@ class PoseGraph:
         all_reg = self.reg + self.overlap_reg
         if not exclude_registration and all_reg:
             rank, world = (0, 1)
-            if group is not None:
+            if comm is not None:  # coxgraph_amd.capi.Comm: RCCL behind the C ABI (what the C++ host uses)
+                rank, world = comm.rank, comm.world
+            elif group is not None:
                 import torch.distributed as dist
                 rank, world = dist.get_rank(group), dist.get_world_size(group)
             Hr = np.zeros((n, n))
@@ -266,27 +268,45 @@ class PoseGraph:
             H_save, g_save = H, g
             H, g = Hr, gr
             mine = [c for k, c in enumerate(all_reg) if k % world == rank and c is not None]
-            batchable = len(mine) >= 2 and all(c.sample_idx is None and hasattr(type(c.reg), "normal_eq_batch") for c in mine)
-            if batchable:  # ONE launch for this rank's constraints (cox_reg_normal_eq_batch)
-                results = type(mine[0].reg).normal_eq_batch([c.reg for c in mine], [poses[c.a] for c in mine], [poses[c.b] for c in mine])
-            else:          # begin them all, then collect: their kernels overlap
-                for c in mine:
-                    c.begin(poses[c.a], poses[c.b])
-                results = [c.finish() for c in mine]
-            for c, res in zip(mine, results):
-                H8, g8, ck = res[0], res[1], res[2]
-                scatter(c.a, c.b, H8[:4, :4], H8[:4, 4:], H8[4:, 4:], g8[:4], g8[4:])
-                cr += ck
+            # A rank whose evaluation fails must still take part in the all-reduce (the others would wait in it until the backend's
+            # timeout): it contributes zeros and one in the buffer's extra "failed ranks" word, and every rank raises.
+            local_error = None
+            try:
+                batchable = len(mine) >= 2 and all(c.sample_idx is None and hasattr(type(c.reg), "normal_eq_batch") for c in mine)
+                if batchable:  # ONE launch for this rank's constraints (cox_reg_normal_eq_batch)
+                    results = type(mine[0].reg).normal_eq_batch([c.reg for c in mine], [poses[c.a] for c in mine], [poses[c.b] for c in mine])
+                else:          # begin them all, then collect: their kernels overlap
+                    for c in mine:
+                        c.begin(poses[c.a], poses[c.b])
+                    results = [c.finish() for c in mine]
+                for c, res in zip(mine, results):
+                    H8, g8, ck = res[0], res[1], res[2]
+                    scatter(c.a, c.b, H8[:4, :4], H8[:4, 4:], H8[4:, 4:], g8[:4], g8[4:])
+                    cr += ck
+            except Exception as e:  # noqa: BLE001
+                if group is None and comm is None:
+                    raise
+                local_error = e
+                Hr[:] = 0.0
+                gr[:] = 0.0
+                cr = 0.0
             H, g = H_save, g_save
-            if group is not None:  # (also with one rank: the same code path a rehearsal on one GPU exercises)
+            if comm is not None:
+                buf = comm.allreduce_f64(np.concatenate([Hr.reshape(-1), gr, [cr, 0.0 if local_error is None else 1.0]]))
+                if buf[-1] != 0.0:
+                    raise RuntimeError(f"registration constraints: evaluation failed on {int(buf[-1])} rank(s)") from local_error
+                Hr, gr, cr = buf[:n * n].reshape(n, n), buf[n * n:n * n + n], float(buf[-2])
+            elif group is not None:  # (also with one rank: the same code path a rehearsal on one GPU exercises)
                 import torch
                 import torch.distributed as dist
-                buf = torch.from_numpy(np.concatenate([Hr.reshape(-1), gr, [cr]]))
+                buf = torch.from_numpy(np.concatenate([Hr.reshape(-1), gr, [cr, 0.0 if local_error is None else 1.0]]))
                 if dist.get_backend(group) == "nccl":
                     buf = buf.cuda()
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
                 buf = buf.cpu().numpy()
-                Hr, gr, cr = buf[:n * n].reshape(n, n), buf[n * n:n * n + n], float(buf[-1])
+                if buf[-1] != 0.0:
+                    raise RuntimeError(f"registration constraints: evaluation failed on {int(buf[-1])} rank(s)") from local_error
+                Hr, gr, cr = buf[:n * n].reshape(n, n), buf[n * n:n * n + n], float(buf[-2])
             H += Hr
             g += gr
             cost += cr
@@ -298,7 +318,7 @@ class PoseGraph:
         return cost, g, H, free
 
     # ---- ceres::Solve as coxgraph configures it (backend/pose_graph.h:56-68) ---------------------------------------------
-    def optimize(self, exclude_registration=False, options=None, group=None):
+    def optimize(self, exclude_registration=False, options=None, group=None, comm=None):
         opt = options or TrustRegionOptions()
         idx, free = self._free_index()
         base = {k: v.copy() for k, v in self.poses.items()}
@@ -310,7 +330,7 @@ class PoseGraph:
             return poses
 
         def evaluate(x):
-            cost, g, H, _ = self.build(unpack(x), exclude_registration, group)
+            cost, g, H, _ = self.build(unpack(x), exclude_registration, group, comm)
             return cost, g, H
 
         def plus(x, delta):  # x, y, z plain; yaw: voxgraph's AngleLocalParameterization (normalised sum)

@@ -41,7 +41,8 @@ typedef enum cox_status {
   COX_ERR_INDEX_RANGE = -5,     /* a voxel index left the +-2^20 range the packed keys support */
   COX_ERR_UNSUPPORTED = -6,     /* valid in the reference, not implemented by this engine (yet) */
   COX_ERR_BUFFER_TOO_SMALL = -7,
-  COX_ERR_INTERNAL = -8
+  COX_ERR_INTERNAL = -8,
+  COX_ERR_COMM = -9             /* an RCCL call failed (communicator set-up or a collective); RCCL's own message goes to stderr */
 } cox_status;
 
 typedef struct cox_layer cox_layer_t;           /* voxblox::Layer<TsdfVoxel> on one GPU */
@@ -361,8 +362,22 @@ void cox_comm_destroy(cox_comm_t* comm);
 int cox_comm_rank(const cox_comm_t* comm, int* rank, int* world);
 /* host buffer in, host buffer out (the payload is KBs and the solver reads it on the host) */
 int cox_comm_allreduce_f64(cox_comm_t* comm, double* buf, uint64_t n);
-/* recv_dev holds world * bytes_per_rank bytes, rank r's part at offset r * bytes_per_rank; device pointers */
+/* recv_dev holds world * bytes_per_rank bytes, rank r's part at offset r * bytes_per_rank; device pointers.  The collective runs on
+ * the communicator's own stream behind an event on the stream that produced send_dev (_on: the caller names it; without: the
+ * legacy default stream, which orders behind the engine's synchronous exports and behind torch's default stream) -- never behind
+ * a device-wide synchronisation.  Returns when the gathered bytes are in recv_dev. */
 int cox_comm_allgather_dev(cox_comm_t* comm, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+int cox_comm_allgather_dev_on(cox_comm_t* comm, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, void* producer_stream);
+
+/* ---- process set-up ---------------------------------------------------------------------------------------
+ * An integrator keeps frames in flight on four HIP streams, and the ROCm runtime multiplexes a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (4 by default, shared with every other HIP user of the process): stages that share a queue
+ * run back to back (6.1 k instead of 7.5 k frames/s at 5 cm).  The variable is read when the HIP runtime initialises, so a host
+ * calls cox_runtime_prepare() FIRST -- before its first HIP call, before it loads anything that makes one (torch, ...).  It sets
+ * GPU_MAX_HW_QUEUES=16 unless the variable is already set, touches nothing else, and returns 1 when the runtime of this process
+ * was not yet initialised by this library's knowledge (0: too late to have an effect, or the caller's own value stands).  The
+ * library no longer does this behind the host's back when it is loaded (round 2 did: a setenv from a static constructor). */
+int cox_runtime_prepare(void);
 
 /* ---- recover mode: mesh-with-history -> per-pose point clouds -> integrator ------------------ */
 /* voxblox::MeshConverter (coxgraph/include/coxgraph/map_comm/mesh_converter.h:22-289), the front end of the only

@@ -68,6 +68,24 @@ def main():
         results.append((cost, g.copy(), H.copy()))
     assert results[0][0] > 0 and np.count_nonzero(results[0][2]) > 0
     assert results[0][0] == results[1][0] and np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+    # the same two collectives through the engine's own communicator (cox_comm_*: RCCL behind the C ABI, what the C++ host and
+    # bench.py's COX_DIST_BACKEND=rccl-capi use): the gathered bytes and the reduced normal equations are the same
+    from coxgraph_amd.capi import Comm  # noqa: E402
+    comm = Comm(eng, 0, 0, 1, Comm.unique_id(eng))
+    c_idx, c_vox, c_pts = (torch.zeros((1,) + tuple(t.shape), dtype=t.dtype, device="cuda") for t in (idx_t, vox_t, pts_t))
+    cur = torch.cuda.current_stream().cuda_stream
+    for src, dst in ((idx_t, c_idx), (vox_t, c_vox), (pts_t, c_pts)):
+        comm.allgather_dev(src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size(), cur)
+    assert torch.equal(c_idx, g_idx) and torch.equal(c_vox, g_vox) and torch.equal(c_pts, g_pts)
+    pg = PoseGraph()
+    pg.add_node(0, [0.0, 0.0, 0.0, 0.0], constant=True)
+    pg.add_node(1, [0.02, -0.01, 0.0, 0.002])
+    reg = Registration(eng, pa, lb)
+    reg.draw_samples(int(0.3 * pa.n), 1234)
+    pg.reg.append(RegistrationConstraint(0, 1, reg))
+    cost_c, g_c, H_c, _ = pg.build({k: v.copy() for k, v in pg.poses.items()}, comm=comm)
+    assert cost_c == results[0][0] and np.array_equal(g_c, results[0][1]) and np.array_equal(H_c, results[0][2])
+    comm.close()
     tt = torch.tensor([1.5, 2.0], dtype=torch.float64, device="cuda")
     dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
     dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)

@@ -182,3 +182,36 @@ def test_submap_exchange_and_inter_robot_registration_over_gloo(oracle):
     cost, g, H, _ = pg.build({k: v.copy() for k, v in pg.poses.items()})
     assert cost > 0 and np.count_nonzero(H) > 0      # neighbouring clients overlap: the constraints have correspondences
     assert np.isclose(cost, res[0]["cost"], rtol=1e-12) and np.allclose(g, res[0]["g"], rtol=1e-10, atol=1e-12) and np.allclose(H, res[0]["H"], rtol=1e-10, atol=1e-12)
+
+
+def _worker_failing_rank(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    sys.path.insert(0, ROOT)
+    from coxgraph_amd.capi import Engine
+    eng = Engine(os.path.join(ROOT, "oracle", "libcoxoracle.so"), "coxo_")
+    g, keep = _problem(eng)
+    if rank == 1:  # this rank's share of the constraints cannot be evaluated (a pending begin without its finish)
+        mine = [c for k, c in enumerate(g.pose_graph.reg) if k % world == rank]
+        mine[0].reg.normal_eq_begin(np.zeros(4), np.zeros(4))
+    try:
+        g.pose_graph.build({k: v.copy() for k, v in g.pose_graph.poses.items()}, group=dist.group.WORLD)
+        out[rank] = "no error"
+    except RuntimeError as e:
+        out[rank] = str(e)
+    dist.barrier()  # both ranks are still in step: nobody is left waiting inside the all-reduce
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_leave_the_others_in_the_all_reduce(oracle):
+    """a rank that cannot evaluate its constraints still joins the all-reduce (zero contribution + an error count), and
+    EVERY rank raises -- nobody waits for ever."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_failing_rank, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert "failed on 1 rank" in res[0] and "failed on 1 rank" in res[1], res
