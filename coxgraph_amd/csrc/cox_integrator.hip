@@ -2150,6 +2150,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   }
   COX_TRY(ensure_capacity(I, n));
   COX_TRY(follow_layer(I));
+  const bool foreign_writer = (n != 0 || I->method == COX_METHOD_FAST) && cox_layer_order_writer(Lh, I);
   I->last = cox_frame_stats{};
   I->last.n_points = n;
   I->last_has_counts = false;
@@ -2190,7 +2191,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
     }
     if (in.consumed) COX_HIP(hipEventRecord(in.consumed, I->st[0]));
     COX_HIP(hipGetLastError());
-    auto back = [ctx, job]() -> int {
+    auto back = [ctx, job, foreign_writer]() -> int {
       cox_integrator* I = ctx.I;
       FrameSet& F = *ctx.F;
       RecordSet& S = *ctx.S;
@@ -2200,6 +2201,7 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
       COX_TRY(fast_solve(ctx, job));
       COX_HIP(hipEventRecord(F.hand[2], I->st[1]));
       COX_HIP(hipStreamWaitEvent(I->st[3], F.hand[2], 0));
+      if (foreign_writer) cox_layer_wait_writes(Lh, I->st[3]);  // another integrator wrote this layer last
       COX_TRY(run_stage(3, ctx));  // touch / emit, record partition, apply on st[3] == st[4] == st[5]
       COX_TRY(run_stage(4, ctx));
       COX_TRY(run_stage(5, ctx));
@@ -2247,12 +2249,13 @@ static int integrate_device(cox_integrator* I, const float T[7], const float* xy
   if (in.consumed) COX_HIP(hipEventRecord(in.consumed, s_m));
   COX_HIP(hipGetLastError());
   // T, R, U (layer update): on the submission thread when there is one
-  auto stage_b = [ctx, chain]() -> int {
+  auto stage_b = [ctx, chain, foreign_writer]() -> int {
     cox_integrator* I = ctx.I;
     FrameSet& F = *ctx.F;
     RecordSet& S = *ctx.S;
     cox_layer* Lh = I->layer;
     if (S.used && I->st[3] != I->st[5]) COX_HIP(hipStreamWaitEvent(I->st[3], S.done, 0));  // frame t-3's apply is done with this record set
+    if (foreign_writer) cox_layer_wait_writes(Lh, I->st[3]);  // another integrator wrote this layer last: stage T (block touches) follows its frames
     COX_TRY(chain(ctx, 3));
     COX_TRY(chain(ctx, 4));
     COX_TRY(chain(ctx, 5));

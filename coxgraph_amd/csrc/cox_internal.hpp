@@ -63,6 +63,11 @@ struct cox_layer {
   // (cox_reg_*, clones) wait for it instead of for the whole device
   hipEvent_t last_write = nullptr;
   bool has_write = false;
+  // Several integrators may drive one layer (a merged one for the live stream, a fast one for recover mode ...), each on streams of
+  // its own: a frame whose integrator is not the one that wrote last orders its first layer-touching stage behind last_write
+  // (cox_layer_order_writer), so the frames of different integrators reach the layer in call order, as they do in voxblox, and the
+  // last recorded event stands for every frame before it.
+  const void* last_writer = nullptr;
 };
 
 // make stream s wait for every frame enqueued so far on the layer (no-op when nothing was enqueued)
@@ -70,6 +75,16 @@ static inline void cox_layer_wait_writes(const cox_layer* L, hipStream_t s) {
   if (L->has_write && L->last_write) (void)hipStreamWaitEvent(s, L->last_write, 0);
 }
 int cox_internal_layer_reserve(cox_layer* L, u64 capacity_blocks);
+void cox_drain_submitters();
+// Called by an integrator's entry point before it enqueues a frame: true when another integrator wrote the layer last -- its
+// submission thread has then enqueued (and recorded last_write behind) everything it was handed, and the caller makes the
+// stream of its first layer-touching stage wait for last_write.
+static inline bool cox_layer_order_writer(cox_layer* L, const void* writer) {
+  const bool foreign = L->last_writer != nullptr && L->last_writer != writer && L->has_write;
+  if (foreign) cox_drain_submitters();
+  L->last_writer = writer;
+  return foreign;
+}
 
 // voxgraph registration point set of a submap, resident on one GPU
 struct cox_regpoints {

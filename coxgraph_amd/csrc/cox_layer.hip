@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(256) k_rehash(const u64* __restrict__ block_ke
 int cox_internal_layer_reserve(cox_layer* L, u64 capacity_blocks) {
   if (capacity_blocks <= L->capacity) return COX_OK;
   if (capacity_blocks > (1ull << 26)) return COX_ERR_INVALID_ARG;
+  // every integrator on this layer (not only the one that asks) may have half of a frame waiting in its submission thread: those
+  // jobs read the buffers that are about to be freed.  Enqueued they are covered by the device-wide sync below.  
+  cox_drain_submitters();
   u32 nb, err;
   int st = layer_read_counters(L, &nb, &err);  // device-wide sync
   if (st != COX_OK) return st;

@@ -438,6 +438,7 @@ int cox_proj_integrate(cox_projective* P, const float T[7], const float* xyz_dev
   pp.frame_id = ++L->frame_id;
   const ProjLayer PL{L->voxels, L->ht_keys, L->ht_vals, L->ht_stamp, L->block_keys, L->d_nblocks, L->ht_cap - 1, static_cast<u32>(L->capacity)};
   const size_t px = static_cast<size_t>(pp.rows) * pp.cols;
+  if (cox_layer_order_writer(L, P)) cox_layer_wait_writes(L, s);  // another integrator wrote this layer last
   COX_HIP(hipMemsetAsync(P->range, 0x7F, sizeof(u32) * px, s));
   COX_HIP(hipMemsetAsync(P->cnt, 0, sizeof(ProjCounters), s));
   hipLaunchKernelGGL(k_proj_points, dim3(static_cast<u32>((n + 255) / 256)), dim3(256), 0, s, pp, xyz_dev, P->range, PL, P->touched_slots, P->cnt, L->d_err);

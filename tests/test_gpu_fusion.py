@@ -689,3 +689,34 @@ def test_depth_stream_without_host_sync(hip, method):
     ja, va = a.download()
     jb, vb = b.download()
     assert np.array_equal(ja, jb) and np.array_equal(va, vb)
+
+
+def test_integrators_sharing_a_layer_asynchronously_with_pool_growth(hip, oracle):
+    """two or three integrators alternate on ONE layer through the asynchronous device path (frames in flight on each
+    integrator's own streams, half of every frame waiting in its submission thread), with a pool so small that it is
+    reallocated several times on the way -- by whichever integrator happens to notice.  Frames of different integrators must
+    reach the layer in call order and nobody may touch a freed pool: the layer equals the oracle's, bit for bit."""
+    import torch
+    n_frames, sub = 36, 4
+    frames = [synth.make_frame(3 * t) for t in range(n_frames)]
+    methods = ("merged", "fast", "merged", "simple")
+    dev = [(T, torch.from_numpy(np.ascontiguousarray(p[::sub])).cuda(), torch.from_numpy(np.ascontiguousarray(c[::sub])).cuda()) for T, p, c, _ in frames]
+    torch.cuda.synchronize()
+    res = []
+    for eng in (hip, oracle):
+        cfg = eng.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
+        layer = Layer(eng, 0.05, capacity_blocks=64)  # the first frame alone nearly fills it
+        ints = [Integrator(eng, layer, cfg, m) for m in methods]
+        for t, (T, p, c, _) in enumerate(frames):
+            k = (t // 2) % len(ints)  # two frames in a row per integrator, then the next one
+            if eng is hip:
+                ints[k].integrate_points_dev(T, dev[t][1].data_ptr(), dev[t][2].data_ptr(), dev[t][1].shape[0])
+            else:
+                ints[k].integrate_points(T, p[::sub], c[::sub])
+        for i in ints:
+            i.sync()
+        res.append(layer)
+        if eng is hip:
+            assert layer.capacity() > 64  # it grew
+    rep = compare_layers(res[0], res[1])
+    assert rep["blocks"] > 64 and rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
