@@ -95,3 +95,92 @@ def test_projective_needs_its_sensor_model(oracle):
     with pytest.raises(CoxError) as e:
         integ.deintegrate_points(IDENT, np.zeros((1, 3), np.float32))
     assert e.value.status == -6
+
+
+# ---- how many voxels a depth camera observes through the yaml files' lidar model: an expectation that owes nothing to the integrator ----
+def analytic_range(origin, dirs):
+    """distance along unit directions from `origin` to the synthetic room's walls / sphere (float64)"""
+    from coxgraph_amd import synth
+    t = np.full(dirs.shape[0], np.inf)
+    for ax in range(3):
+        d = dirs[:, ax]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for bound in (synth.ROOM_MIN[ax], synth.ROOM_MAX[ax]):
+                tt = (bound - origin[ax]) / d
+                t = np.minimum(t, np.where((tt > 1e-9) & np.isfinite(tt), tt, np.inf))
+    oc = origin - synth.SPHERE_C
+    b = 2.0 * dirs @ oc
+    disc = b * b - 4 * (float(oc @ oc) - synth.SPHERE_R ** 2)
+    with np.errstate(invalid="ignore"):
+        ts = (-b - np.sqrt(np.where(disc >= 0, disc, np.nan))) / 2
+    return np.minimum(t, np.where((disc >= 0) & (ts > 1e-9), ts, np.inf))
+
+
+def expected_observed_voxels(voxel, frame_ids, trunc, min_ray, max_ray, carving, const_weight=True, deintegrated=None, w=640, h=480):
+    """Voxel centres a projective integrator must end up observing after the synthetic frames `frame_ids`, from the scene's geometry
+    alone: inside a frame's field of view, within the ray limits, and with sdf = (analytic range along the voxel's bearing) - |voxel|
+    >= -truncation (<= truncation too without carving).  `deintegrated`: that frame is taken out again afterwards -- it removes its
+    own weight (1, or 1 / r^2 without const weight), and a voxel left with less than a weight of 1 goes back to unobserved
+    (upstream's de-integration rule as restated in oracle/cox_oracle_projective.hpp)."""
+    from coxgraph_amd import synth
+    fx, fy, cx, cy = synth.INTRINSICS[(w, h)]
+    g = [np.arange(np.floor(lo / voxel) - 2, np.ceil(hi / voxel) + 2) for lo, hi in zip(synth.ROOM_MIN - 0.5, synth.ROOM_MAX + 0.5)]
+    X, Y, Z = np.meshgrid(*g, indexing="ij")
+    C_ = (np.stack([X, Y, Z], -1).reshape(-1, 3) + 0.5) * voxel
+    weight = np.zeros(len(C_))
+    removed = np.zeros(len(C_))
+    for t in frame_ids:
+        R, o, _ = synth.camera_pose(t)
+        v = C_ - o
+        r = np.linalg.norm(v, axis=1)
+        pc = v @ R  # camera frame (z forward)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * pc[:, 0] / pc[:, 2] + cx
+            vv = fy * pc[:, 1] / pc[:, 2] + cy
+        rng = analytic_range(o, v / r[:, None])
+        sdf = rng - r
+        ok = (pc[:, 2] > 0) & (u >= 0) & (u <= w - 1) & (vv >= 0) & (vv <= h - 1) & (rng >= min_ray) & (rng <= max_ray) & (r >= min_ray) & (sdf >= -trunc)
+        if not carving:
+            ok &= sdf <= trunc
+        obs = np.where(ok, 1.0 if const_weight else 1.0 / np.maximum(r, 1e-9) ** 2, 0.0)
+        weight += obs
+        if t == deintegrated:
+            removed = obs
+    seen = weight > 0
+    if deintegrated is not None:
+        seen &= ~((removed > 0) & (weight - removed < 1.0))
+    return int(seen.sum())
+
+
+@pytest.mark.parametrize("voxel", [0.10])
+def test_depth_camera_through_the_lidar_model_observes_what_the_geometry_says(oracle, voxel):
+    """The reference's yaml files give the projective integrator 1280 x 960 pixels over 360 degrees of VERTICAL field of view even for
+    depth cameras (tsdf_server_default.yaml:7-9): in the optical frame (z forward) that is a polar image around the optical axis --
+    altitude = asin(z / r) is 60 to 90 degrees, so only ~80 of the 960 rows are ever used.  It still resolves the scene: the count of
+    observed voxels equals the geometric expectation to a few per cent, before and after a de-integration -- including the variant
+    without const weights, where de-integrating one frame sends every voxel it saw back to unobserved unless the other frames left
+    it a weight of 1 or more (1 / r^2 weights: only surfaces nearer than ~1.7 m).  (the old guard `observed >
+    1000` was right for that variant, for this reason -- not a symptom.)"""
+    from coxgraph_amd import synth
+    ov = synth.integrator_overrides(voxel)
+    frames = [synth.make_frame(t)[:2] for t in (0, 10, 20, 30)]
+    frames = [(T, p[::2]) for T, p in frames]
+    kw = dict(sensor_horizontal_resolution=1280, sensor_vertical_resolution=960, sensor_vertical_field_of_view_degrees=360.0,
+              default_truncation_distance=ov["default_truncation_distance"], min_ray_length_m=ov["min_ray_length_m"], max_ray_length_m=ov["max_ray_length_m"])
+    for extra in (dict(), dict(use_const_weight=0, use_weight_dropoff=0, voxel_carving_enabled=0)):
+        layer = Layer(oracle, voxel, capacity_blocks=8192)
+        integ = Integrator(oracle, layer, proj_config(oracle, **dict(kw, **extra)), "projective")
+        for T, p in frames:
+            integ.integrate_points(T, p, None)
+        n_all = int((words_to_fields(layer.download()[1])[1] > 0).sum())
+        integ.deintegrate_points(*frames[0])
+        n_after = int((words_to_fields(layer.download()[1])[1] > 0).sum())
+        geo = dict(trunc=kw["default_truncation_distance"], min_ray=kw["min_ray_length_m"], max_ray=kw["max_ray_length_m"],
+                   carving=extra.get("voxel_carving_enabled", 1), const_weight=bool(extra.get("use_const_weight", 1)))
+        e_all = expected_observed_voxels(voxel, (0, 10, 20, 30), **geo)
+        e_after = expected_observed_voxels(voxel, (0, 10, 20, 30), deintegrated=0, **geo)
+        print(extra, n_all, e_all, n_after, e_after)
+        assert abs(n_all - e_all) <= 0.08 * e_all, (extra, n_all, e_all)
+        # (without const weights the survivors are a thin shell -- voxels outside the removed frame's field of view, or nearer than
+        # ~1.7 m -- whose count hangs on the image's edge pixels: a looser band there)
+        assert abs(n_after - e_after) <= (0.08 if geo["const_weight"] else 0.35) * e_after, (extra, n_after, e_after)
