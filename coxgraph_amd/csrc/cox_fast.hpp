@@ -270,9 +270,9 @@ __global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ sk
 // a small grid (kFastRelaxGroups workgroups, far fewer than the chip holds at once) stays resident and meets at a barrier
 // after every pass.  The barrier cannot hang: a workgroup that waits longer than kFastBarrierPolls polls gives up, raises `abort`,
 // everybody leaves, and the frame is redone by k_fast_sequential -- exact either way, and no host round trip.
-//   short lists (<= lpr steps: every list of round 0, the lists of the rays that did not grow in round 1): lpr lanes per ray,
-//     64 / lpr rays per wave; the collision flags of a ray are one ballot, its stop a few bit operations
-//   long lists (round 1: the rays that got their whole walk): one wave per ray, up to 256 steps tested at once
+//   short lists (<= 32 steps: every list of round 0, later the lists of the rays that did not get their whole walk): eight lanes
+//     per ray, eight rays per wave, eight steps at a time; the collision flags of a ray are one ballot, its stop a few bit operations
+//   long lists (the rays that got their whole walk): one workgroup per ray, 512 steps tested at once
 constexpr u32 kFastRelaxGroups = 128, kFastRelaxThreads = 512;
 constexpr u32 kFastBarrierPolls = 2000000;  // x ~0.5 us: about a second
 constexpr u32 kFastMaxPasses = 4096;
@@ -316,23 +316,27 @@ __device__ __forceinline__ bool fast_grid_barrier(FastBarrier* b, u32 pass, u32*
 // first step at which more than max_collisions collisions in a row have happened, from the collision flags of a list of ns <= 32 steps
 __device__ __forceinline__ u32 fast_stop_from_bits(u32 m, u32 ns, int max_collisions) {
   u32 x = m;
-  for (int k = 1; k <= max_collisions && x; ++k) x &= m >> k;  // bit s: collisions at s, s + 1, ..., s + max_collisions
+  for (int k = 1; k <= max_collisions && k < 32 && x; ++k) x &= m >> k;  // bit s: collisions at s, s + 1, ..., s + max_collisions
+  if (max_collisions >= 32) x = 0;                                       // (a list of 32 steps cannot hold that many in a row)
   return x ? static_cast<u32>(__ffs(static_cast<int>(x))) - 1u + static_cast<u32>(max_collisions) : ns;
 }
+constexpr u32 kFastShortMax = 32;  // lists up to this long: eight lanes per ray, eight steps at a time; longer ones: one workgroup per ray
 __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, int max_collisions, const u32* __restrict__ list_len, const u32* __restrict__ nfull,
-                                                                  const u64* __restrict__ table_obs, u32* reach, FastCtl* ctl, int round, u32 lpr,
+                                                                  const u64* __restrict__ table_obs, u32* reach, FastCtl* ctl, int round,
                                                                   const u32* __restrict__ long_list, const u32* __restrict__ d_n_rays, int fences) {
   __shared__ u32 lds_ok;
+  __shared__ u64 lds_bits[kFastRelaxThreads / 64];
   FastBarrier* bar = &ctl->bar[round];
   if (ctl->overflow || (round > 0 && ctl->grew[round] == 0u)) return;  // (uniform over the grid: nobody waits for anybody)
   const u32 n_rays = *d_n_rays;
   const u32 n_long = round > 0 ? ctl->n_long : 0u;
   const u32 lane = lane_id();
   const u32 n_waves = (gridDim.x * blockDim.x) >> 6;
+  const u32 wave_in_wg = uniform_u32(threadIdx.x >> 6);
   const u32 wave0 = uniform_u32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const u32 per_wave = 64u / lpr;     // rays of a wave in the short-list part (lpr = 8, 16 or 32)
-  const u32 sub = lane / lpr, s = lane % lpr;
-  const u64 sub_mask = (lpr == 32u ? 0xFFFFFFFFull : ((1ull << lpr) - 1ull));
+  const u32 sub = lane >> 3, sl = lane & 7u;  // eight rays per wave, eight lanes per ray
+  const bool wide_ok = max_collisions < 63;   // (the 512-step chunks of the long lists test runs with 64-bit shifts)
+  u64 t_mark = wall_clock64(), t_work = 0, t_wait = 0;  // workgroup 0 keeps the time (100 MHz ticks): a pass's own work / its wait at the barrier
   for (u32 pass = 0; pass < kFastMaxPasses; ++pass) {
     const u32 f = pass % 3u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the flags of the pass after this one: last read behind the barrier before the previous one
@@ -340,33 +344,39 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
       (void)atomicAnd(&bar->want[(pass + 1u) % 3u], 0u);
     }
     bool any = false, wants = false;
-    // short lists
-    for (u32 g = wave0; g * per_wave < n_rays; g += n_waves) {
-      const u32 r = g * per_wave + sub;
-      u32 ns = 0, off = 0;
+    // ---- short lists (every list of round 0; later the lists of the rays that did not get their whole walk) --------------------
+    // Eight steps at a time, and of the first eight only the steps up to the ray's present stop: a stable ray (most of them, from
+    // the second pass on) is confirmed by those alone, and they are the cheap ones -- near the surface every slot's run is full of
+    // performed visits, while the voxels in front of it, steps 4 .. 7 of every ray around, have runs of nothing but unperformed
+    // visits that a look-up has to walk through (a wave waits for its longest walk).  Only a ray that does NOT stop within what has
+    // been looked at goes on to the next steps of its list.
+    for (u32 g = wave0; g * 8u < n_rays; g += n_waves) {
+      const u32 r = g * 8u + sub;
+      u32 ns = 0, off = 0, old = 0;
+      bool short_ray = false;
       if (r < n_rays) {
         ns = list_len[r];
         off = V.voff[r];
-        if (ns > lpr) ns = 0xFFFFFFFFu;  // a long list: the wave-per-ray part below
+        old = fast_ld(&reach[r]);
+        short_ray = ns <= kFastShortMax;
       }
-      // The steps up to the ray's present stop first: a stable ray (most of them, from the second pass on) is confirmed by those
-      // alone, and they are the cheap ones -- near the surface every slot's run is full of performed visits, while the voxels in
-      // front of it, steps 4 .. 7 of every ray around, have runs of nothing but unperformed visits that a look-up has to walk
-      // through (a wave waits for its longest walk).  Only a ray that does NOT stop within them looks at the rest of its list.
-      const bool short_ray = r < n_rays && ns != 0xFFFFFFFFu;
-      const u32 old = short_ray ? fast_ld(&reach[r]) : 0u;
-      const u32 first = min(ns, old + 1u);  // steps [0, first)
-      const u32 pos = (short_ray && s < ns) ? V.pos_of[off + s] : 0u;
-      bool coll = short_ray && s < first && fast_collision(V, reach, table_obs, pos);
-      u32 m = static_cast<u32>((__ballot(coll) >> (sub * lpr)) & sub_mask);
-      u32 stop = fast_stop_from_bits(m, ns, max_collisions);
-      const bool more = short_ray && stop >= first && first < ns;  // (uniform over the ray's lanes)
-      if (__ballot(more)) {
-        if (more && s >= first && s < ns) coll = fast_collision(V, reach, table_obs, pos);
-        m = static_cast<u32>((__ballot(coll) >> (sub * lpr)) & sub_mask);
-        if (more) stop = fast_stop_from_bits(m, ns, max_collisions);
+      const u32 first = min(ns, old + 1u);
+      u32 bits = 0, evaluated = 0, stop = ns;
+      for (;;) {
+        const bool active = short_ray && stop == ns && evaluated < ns;
+        if (!__ballot(active)) break;
+        const u32 bound = min(evaluated + 8u, evaluated < first ? first : ns);
+        const u32 st = evaluated + sl;
+        const bool coll = active && st < bound && fast_collision(V, reach, table_obs, V.pos_of[off + st]);
+        const u32 m8 = static_cast<u32>((__ballot(coll) >> (sub * 8u)) & 0xFFull);
+        if (active) {
+          bits |= m8 << evaluated;
+          evaluated = bound;
+          const u32 found = fast_stop_from_bits(bits, ns, max_collisions);  // (steps not looked at yet are zeros: a run that completes is real)
+          if (found != ns) stop = found;
+        }
       }
-      if (short_ray && s == 0) {
+      if (short_ray && sl == 0) {
         if (stop == ns && ns < nfull[r]) wants = true;
         if (stop != old) {
           __hip_atomic_store(&reach[r], stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -374,40 +384,43 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
         }
       }
     }
-    // long lists: up to 256 steps of a walk are tested at once; the reference's "more than max_collisions collisions in a row" is
-    // the first lane whose run of set bits (continued from the previous 64 steps) is long enough
-    for (u32 q = wave0; q < n_long; q += n_waves) {
+    // ---- long lists (the few rays -- a few dozen per frame at 5 cm -- that got their whole walk): ONE WORKGROUP per ray, 512 steps
+    // at a time, one step per lane.  (One wave per ray, four steps per lane one after the other, was the pass: 94 us instead of 36.)
+    for (u32 q = blockIdx.x; q < n_long; q += gridDim.x) {
       const u32 r = uniform_u32(long_list[q]);
-      const u32 ns = uniform_u32(list_len[r]), off = uniform_u32(V.voff[r]);
-      u32 carry = 0, stop = ns;
-      // every tested step costs half a dozen gathers, so a ray that stopped early last time is tested in growing segments: 16 steps,
-      // the rest of the first 64, then 256 at a time (four independent gathers per lane in flight); one that went far (most of the
-      // rays that have their whole walk) starts with 256: one batch of dependent round trips instead of three
-      u32 base = 0, seg = (fast_ld(&reach[r]) >= 48u) ? 256u : 16u;
-      while (base < ns && stop == ns) {
-        const u32 len = uniform_u32(min(seg, ns - base));
-        bool coll[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const u32 t = 64u * j + lane;
-          coll[j] = (t < len) && fast_collision(V, reach, table_obs, V.pos_of[off + base + t]);
+      const u32 ns = uniform_u32(list_len[r]);
+      if (ns <= kFastShortMax) continue;  // (uniform) handled with the short ones
+      const u32 off = uniform_u32(V.voff[r]);
+      u32 stop = ns;
+      u64 prev = 0;  // the collision flags of the 64 steps before this wave's (runs continue across words)
+      for (u32 base = 0; base < ns && stop == ns; base += kFastRelaxThreads) {
+        const u32 st = base + threadIdx.x;
+        const bool coll = st < ns && fast_collision(V, reach, table_obs, V.pos_of[off + st]);
+        const u64 m = __ballot(coll);
+        __syncthreads();  // (the words of the previous chunk have been read)
+        if (lane == 0) lds_bits[wave_in_wg] = m;
+        __syncthreads();
+        if (wide_ok) {
+          for (u32 w = 0; w < kFastRelaxThreads / 64 && stop == ns; ++w) {
+            const u64 mw = lds_bits[w];
+            u64 e = mw;  // bit p: collisions at p, p - 1, ..., p - max_collisions (reaching back into the previous word)
+            for (int k = 1; k <= max_collisions && e; ++k) e &= (mw << k) | (prev >> (64 - k));
+            if (e) stop = base + 64u * w + static_cast<u32>(__ffsll(static_cast<long long>(e))) - 1u;
+            prev = mw;
+          }
+        } else {  // (max_consecutive_ray_collisions of 63 and more: step by step)
+          u32 run = 0;
+          for (u32 w = 0; w < kFastRelaxThreads / 64 && stop == ns; ++w) {
+            const u64 mw = lds_bits[w];
+            for (u32 bit = 0; bit < 64 && stop == ns; ++bit) {
+              run = ((mw >> bit) & 1ull) ? run + 1u : 0u;
+              if (run > static_cast<u32>(max_collisions)) stop = base + 64u * w + bit;
+            }
+          }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (stop != ns || 64u * j >= len) break;
-          const u32 cnt_in = uniform_u32(min(64u, len - 64u * j));  // lanes of this group that hold a step
-          const u64 m = __ballot(coll[j]);
-          // length of the run of collisions that ends at this lane
-          const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-          const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
-          const u64 hit = __ballot(coll[j] && run > static_cast<u32>(max_collisions));
-          if (hit) stop = base + 64u * j + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
-          carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), static_cast<int>(cnt_in - 1u)));
-        }
-        base += len;
-        seg = (base < 64u) ? 64u - base : 256u;
+        stop = min(stop, ns);  // (flags past the end of the list are zero, so this only guards the arithmetic)
       }
-      if (lane == 0) {
+      if (threadIdx.x == 0) {
         if (stop == ns && ns < nfull[r]) wants = true;
         if (stop != fast_ld(&reach[r])) {
           __hip_atomic_store(&reach[r], stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -418,11 +431,23 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
     // one word per flag for the whole grid: only the first few waves that have something to say write it
     if (__ballot(any) && lane == 0 && __hip_atomic_load(&bar->moved[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) (void)atomicOr(&bar->moved[f], 1u);
     if (__ballot(wants) && lane == 0 && __hip_atomic_load(&bar->want[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) (void)atomicOr(&bar->want[f], 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const u64 t = wall_clock64();
+      t_work += t - t_mark;
+      t_mark = t;
+    }
     if (!fast_grid_barrier(bar, pass, &lds_ok, fences)) return;  // gave up: settled[round] stays 0
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const u64 t = wall_clock64();
+      t_wait += t - t_mark;
+      t_mark = t;
+    }
     if (__hip_atomic_load(&bar->moved[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {  // a pass that moved nothing: every ray is at the fixed point
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->want_more[round] = __hip_atomic_load(&bar->want[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctl->passes[round] = pass + 1u;
+        ctl->ticks_work[round] = static_cast<u32>(t_work);
+        ctl->ticks_wait[round] = static_cast<u32>(t_wait);
         ctl->settled[round] = 1u;
       }
       return;
@@ -563,6 +588,16 @@ __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V0, FastVisi
     if (last >= 2) atomicAdd(&stats[6], 1u);
     atomicAdd(&stats[2], ctl->passes[0]);
     atomicAdd(&stats[3], later_passes);
+    u32 tw = 0, tb = 0;
+    for (int r = 0; r < kFastMaxRounds; ++r) {
+      tw += ctl->ticks_work[r];
+      tb += ctl->ticks_wait[r];
+    }
+    atomicAdd(&stats[9], ctl->n_long);
+    atomicAdd(&stats[10], ctl->n_visits[last] >> 4);  // (units of 16 visits)
+    atomicAdd(&stats[11], ctl->n_visits[0] >> 4);
+    atomicAdd(&stats[7], tw);   // 100 MHz ticks workgroup 0 spent in the passes' own work ...
+    atomicAdd(&stats[8], tb);   // ... and waiting at the barriers (the slowest workgroup's work shows up here)
   }
   if (ctl->sequential) return;  // the sequential kernel wrote the table as it went
   const int last = fast_last_round(ctl);

@@ -49,6 +49,7 @@ struct FastCtl {
   u32 settled[kFastMaxRounds];    // [round]: the relaxation reached a pass that moved nothing
   u32 want_more[kFastMaxRounds];  // [round]: at that fixed point some ray is at the end of a list shorter than its walk, unstopped
   u32 passes[kFastMaxRounds];     // [round]: passes the relaxation took
+  u32 ticks_work[kFastMaxRounds], ticks_wait[kFastMaxRounds];  // [round]: 100 MHz ticks workgroup 0 spent working / waiting at the barrier
   u32 grew[kFastMaxRounds];       // [round >= 1]: the round runs (k_fast_grow gave some ray its whole walk)
   u32 scan_n[kFastMaxRounds];     // [round >= 1]: rays the cap scan of the round covers (0 = the round does not run)
   u32 n_long;        // rays with a list longer than cap1 (one wave each), over all rounds
@@ -2043,7 +2044,7 @@ static int fast_solve(const StageCtx& c, const FastJob& job) {
   if (job.wipe_obs) COX_HIP(hipMemsetAsync(X.table_obs, 0, sizeof(u64) * kFastSlots, s));
   {
     TimedRegion t(I, COX_KC_FAST_SWEEPS, s);
-    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V0), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, 0, X.cap0,
+    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V0), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, 0,
                        X.long_list, n_rays, X.fences);
   }
   for (int round = 1; round < X.rounds; ++round) {
@@ -2068,7 +2069,7 @@ static int fast_solve(const StageCtx& c, const FastJob& job) {
                                      2, I->sort_vis1, nullptr, s);
     hipLaunchKernelGGL(k_fast_inverse, dim3(512), dim3(256), 0, s, V1.key[V1.sorted], V1.val[V1.sorted], V1.vray, V1.vhash, V1.voff, V1.pos_of, V1.sinfo, V1.shash,
                        &ctl->n_visits[round], V1.cap);
-    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V1), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, round, X.cap1,
+    hipLaunchKernelGGL(k_fast_relax, dim3(X.relax_groups), dim3(kFastRelaxThreads), 0, s, fast_view(V1), mc, cap, F.rays.nsteps, X.table_obs, reach, ctl, round,
                        X.long_list, n_rays, X.fences);
   }
   // (the relaxation packs (ray, step) into one word: a configuration whose walks or ray counts do not fit takes the sequential kernel)
@@ -2464,9 +2465,9 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
       if (const char* e = std::getenv("COX_FAST_CAP")) {  // candidate steps per ray: "cap0" or "cap0,cap1"
         int a = 0, b = 0;
         const int got = std::sscanf(e, "%d,%d", &a, &b);
-        if (got >= 1 && (a == 8 || a == 16 || a == 32)) I->fast.cap0 = static_cast<u32>(a);  // (lanes per ray in the relaxation: a divisor of the wave)
+        if (got >= 1 && a >= 1 && a <= static_cast<int>(kFastCap0Max)) I->fast.cap0 = static_cast<u32>(a);
         I->fast.cap1 = std::max<u32>(I->fast.cap1, I->fast.cap0);
-        if (got >= 2 && (b == 8 || b == 16 || b == 32) && static_cast<u32>(b) >= I->fast.cap0) I->fast.cap1 = static_cast<u32>(b);
+        if (got >= 2 && b <= static_cast<int>(kFastShortMax) && static_cast<u32>(b) >= I->fast.cap0) I->fast.cap1 = static_cast<u32>(b);
       }
     }
     hipStream_t made[kNumStages] = {};
@@ -2521,9 +2522,9 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     FastState& X = I->fast;
     st = dev_realloc(&X.table_start, kFastSlots);
     if (st == COX_OK) st = dev_realloc(&X.table_obs, kFastSlots);
-    if (st == COX_OK) st = dev_realloc(&X.d_stats, 8);
+    if (st == COX_OK) st = dev_realloc(&X.d_stats, 16);
     if (st == COX_OK && (hipMemset(X.table_start, 0, sizeof(u64) * kFastSlots) != hipSuccess || hipMemset(X.table_obs, 0, sizeof(u64) * kFastSlots) != hipSuccess ||
-                         hipMemset(X.d_stats, 0, sizeof(u32) * 8) != hipSuccess))
+                         hipMemset(X.d_stats, 0, sizeof(u32) * 16) != hipSuccess))
       st = COX_ERR_NO_DEVICE;
     ev(&X.vs0[0].done);
     ev(&X.vs0[1].done);
@@ -2960,19 +2961,23 @@ int cox_integrator_host_time(cox_integrator_t* I, double* ms_total, uint64_t* fr
   return COX_OK;
 }
 
-int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[8]) {
+int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[10]) {
   COX_ENTRY();
   if (!I || !out) return COX_ERR_INVALID_ARG;
   if (I->method != COX_METHOD_FAST || I->proj) return COX_ERR_UNSUPPORTED;
   COX_HIP(hipSetDevice(I->layer->device));
   COX_TRY(sync_all(I));
-  u32 h[8] = {};
+  u32 h[16] = {};
   COX_HIP(hipMemcpy(h, I->fast.d_stats, sizeof(h), hipMemcpyDeviceToHost));
   for (int k = 0; k < 4; ++k) out[k] = h[k];
   out[4] = I->fast.frames;
   out[5] = h[4];
   out[6] = h[5];
   out[7] = h[6];
+  out[8] = static_cast<uint64_t>(h[7]) * 10ull;  // ticks of 10 ns
+  out[9] = static_cast<uint64_t>(h[8]) * 10ull;
+  if (std::getenv("COX_DEBUG")) fprintf(stderr, "[coxgraph_hip] fast: long rays %u, visits of the last round %llu, of round 0 %llu (totals over %llu frames)\n", h[9],
+                                        static_cast<unsigned long long>(h[10]) * 16ull, static_cast<unsigned long long>(h[11]) * 16ull, static_cast<unsigned long long>(I->fast.frames));
   return COX_OK;
 }
 

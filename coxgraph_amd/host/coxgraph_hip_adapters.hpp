@@ -163,6 +163,19 @@ class TsdfIntegrator {
                                freespace_points ? 1 : 0),
           "integratePointCloud");
   }
+  // The same call without waiting for the frame (cox_integrate_points_async): the clouds of a stream are copied to the GPU while the
+  // frames before them are still being fused.  points_C / colors are free again when this returns unless they live in pinned memory
+  // (then: after waitInputs()).  Errors surface at sync() -- voxblox has no return value here either; call sync() before reading the layer.
+  void integratePointCloudAsync(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors, const bool freespace_points = false) {
+    if (!colors.empty() && colors.size() != points_C.size()) throw std::runtime_error("integratePointCloud: points_C.size() != colors.size()");
+    float T[7];
+    T_G_C.pack(T);
+    check(cox_integrate_points_async(h_, T, points_C.empty() ? nullptr : points_C[0].data(), colors.empty() ? nullptr : &colors[0].r, points_C.size(),
+                                     freespace_points ? 1 : 0),
+          "integratePointCloudAsync");
+  }
+  void waitInputs() { check(cox_integrator_wait_inputs(h_), "waitInputs"); }
+  void sync() { check(cox_integrator_sync(h_), "sync"); }
   cox_frame_stats lastFrameStats() const {
     cox_frame_stats s;
     check(cox_integrator_last_stats(h_, &s), "lastFrameStats");
@@ -347,10 +360,33 @@ class RegistrationCostFunction {
     drawn_ = 0;
     check(cox_reg_set_samples(reg_, idx.empty() ? nullptr : idx.data(), idx.size()), "setSampleIndices");
   }
+  // voxgraph's RegistrationCostFunction::Config::jacobian_evaluation_method (kAnalytic is voxgraph's default and what coxgraph's server
+  // runs; kNumeric is its debugging aid: central differences of the residuals, here with a step of 1e-6 per parameter)
+  enum class JacobianEvaluationMethod { kAnalytic = 0, kNumeric };
+  void setJacobianEvaluationMethod(JacobianEvaluationMethod m) { jacobian_method_ = m; }
   // ceres::CostFunction::Evaluate: parameters = {reference pose (x,y,z,yaw), reading pose}, jacobians row-major N x 4
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
-    return cox_reg_evaluate(reg_, parameters[0], parameters[1], nullptr, num_residuals(), residuals, jacobians ? jacobians[0] : nullptr,
-                            jacobians ? jacobians[1] : nullptr) == COX_OK;
+    if (jacobian_method_ == JacobianEvaluationMethod::kAnalytic || !jacobians)
+      return cox_reg_evaluate(reg_, parameters[0], parameters[1], nullptr, num_residuals(), residuals, jacobians ? jacobians[0] : nullptr,
+                              jacobians ? jacobians[1] : nullptr) == COX_OK;
+    const size_t n = static_cast<size_t>(num_residuals());
+    if (residuals && cox_reg_evaluate(reg_, parameters[0], parameters[1], nullptr, n, residuals, nullptr, nullptr) != COX_OK) return false;
+    std::vector<double> rp(n), rm(n);
+    for (int blk = 0; blk < 2; ++blk) {
+      if (!jacobians[blk]) continue;
+      for (int k = 0; k < 4; ++k) {
+        double p[2][4];
+        for (int b2 = 0; b2 < 2; ++b2)
+          for (int c = 0; c < 4; ++c) p[b2][c] = parameters[b2][c];
+        const double h = 1e-6;
+        p[blk][k] = parameters[blk][k] + h;
+        if (cox_reg_evaluate(reg_, p[0], p[1], nullptr, n, rp.data(), nullptr, nullptr) != COX_OK) return false;
+        p[blk][k] = parameters[blk][k] - h;
+        if (cox_reg_evaluate(reg_, p[0], p[1], nullptr, n, rm.data(), nullptr, nullptr) != COX_OK) return false;
+        for (size_t i = 0; i < n; ++i) jacobians[blk][4 * i + k] = (rp[i] - rm[i]) / (2.0 * h);
+      }
+    }
+    return true;
   }
   // fused Gauss-Newton block: H = J^T J (8x8), b = J^T r, cost = |r|^2 / 2
   bool NormalEquations(const double ref[4], const double read[4], double H[64], double b[8], double* cost) const {
@@ -377,6 +413,7 @@ class RegistrationCostFunction {
   cox_reg_t* reg_ = nullptr;
   std::vector<uint32_t> sample_idx_;
   size_t drawn_ = 0;
+  JacobianEvaluationMethod jacobian_method_ = JacobianEvaluationMethod::kAnalytic;
   std::vector<std::shared_ptr<const void>> keepalive_;
 };
 

@@ -243,9 +243,10 @@ int cox_integrator_class_times(cox_integrator_t* integ, double ms[COX_KERNEL_CLA
  * out[0] frames the relaxation did not settle and that were redone by the sequential kernel (exact either way), out[1] frames that
  * needed a second round (some ray got through its capped candidate list), out[2] / out[3] passes of the relaxation in round 0 /
  * the later rounds, out[4] frames, out[5] the part of out[0] in which a ray outgrew its list in the last round, out[6] the part in
- * which a grid barrier gave up, out[7] frames that needed a third round or more.  No reference counterpart (measurement only).
- * Waits for the frames in flight. */
-int cox_integrator_fast_stats(cox_integrator_t* integ, uint64_t out[8]);
+ * which a grid barrier gave up, out[7] frames that needed a third round or more, out[8] / out[9] nanoseconds workgroup 0 of the
+ * relaxation spent in the passes' own work / waiting at their barriers (where the slowest workgroup's work shows).  No reference
+ * counterpart (measurement only).  Waits for the frames in flight. */
+int cox_integrator_fast_stats(cox_integrator_t* integ, uint64_t out[10]);
 
 /* self-test: the merged integrator evaluates its sequential mean with an IEEE division whose divisor-only part is
  * hoisted out of the dependent chain; this compares it bit for bit with the compiler's '/' on n pseudo-random operand

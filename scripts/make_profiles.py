@@ -15,7 +15,7 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 HERE = os.path.dirname(os.path.abspath(__file__))
-COMMON = "--cpu-frames 0 --reg-iters 8 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
+COMMON = "--cpu-frames 0 --reg-iters 8 --other-frames 0 --other-config-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
 FRAMES_TRACE = 320   # warmup 20 + steps 300
 FRAMES_PMC = 40      # the last 40 of the 80 frames (--warmup 20 --steps 60 --no-ramp): steady state
 
@@ -37,6 +37,8 @@ def copy(a, b):
 
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
 copy(os.path.join(src, "bench_line.json"), os.path.join(P, f"{tag}_bench_line.json"))
+if os.path.exists(os.path.join(src, "bench_line_driver.json")):
+    copy(os.path.join(src, "bench_line_driver.json"), os.path.join(P, f"{tag}_bench_line_driver.json"))
 for m in ("merged", "fast"):
     for mode, flag, what in (("async", "", "frames overlapped as in the timed run"), ("serial", " --serial", "one frame in flight")):
         stats = find(f"{m}_{mode}", "kernel_stats.csv")
@@ -91,7 +93,7 @@ def pmc(path, name):
 
 
 for m in ("merged", "fast"):
-    cmd = f"python3 bench.py --method {m} --serial --steps 60 --warmup 20 --cpu-frames 0 --reg-iters 0 --other-frames 0 --pcie-frames 0 --no-profile-pass --no-events --no-ramp"
+    cmd = f"python3 bench.py --method {m} --serial --steps 60 --warmup 20 --cpu-frames 0 --reg-iters 0 --other-frames 0 --other-config-frames 0 --pcie-frames 0 --no-profile-pass --no-events --no-ramp"
     f, fc, order = pmc(find(f"{m}_pmc_fetch", "counter_collection.csv"), "FETCH_SIZE")
     w, wc, _ = pmc(find(f"{m}_pmc_write", "counter_collection.csv"), "WRITE_SIZE")
     lines = [f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another pass) -- {cmd}",

@@ -60,6 +60,46 @@ int main() {
   for (double x : r) worst = std::fmax(worst, std::fabs(x));
   std::printf("registration max |r| = %g\n", worst);
   if (!(worst < 0.06)) return 5;
+  {
+    // jacobian_evaluation_method = numeric (voxgraph's debugging aid): central differences of the residuals agree with the analytic
+    // rows at a pose where the points have moved off the wall (float interpolation inside: 1e-3 is the agreement central differences
+    // of float residuals with a 1e-6 step can have)
+    const double pa[4] = {0.01, -0.02, 0.03, 0.02}, pb[4] = {-0.02, 0.01, -0.01, -0.01};
+    const double* p2[2] = {pa, pb};
+    std::vector<double> r2(pts.size()), nf(4 * pts.size()), nr(4 * pts.size());
+    double* njac[2] = {nf.data(), nr.data()};
+    if (!cost.Evaluate(p2, r.data(), jac)) return 4;
+    cost.setJacobianEvaluationMethod(RegistrationCostFunction::JacobianEvaluationMethod::kNumeric);
+    if (!cost.Evaluate(p2, r2.data(), njac)) return 4;
+    cost.setJacobianEvaluationMethod(RegistrationCostFunction::JacobianEvaluationMethod::kAnalytic);
+    double dj = 0, dr = 0, jmax = 0;
+    for (size_t i = 0; i < nf.size(); ++i) {
+      dj = std::fmax(dj, std::fmax(std::fabs(nf[i] - jf[i]), std::fabs(nr[i] - jr[i])));
+      jmax = std::fmax(jmax, std::fabs(jf[i]));
+    }
+    for (size_t i = 0; i < r.size(); ++i) dr = std::fmax(dr, std::fabs(r[i] - r2[i]));
+    std::printf("numeric vs analytic Jacobian: max |difference| = %g (largest entry %g)\n", dj, jmax);
+    if (dr != 0.0 || !(dj < 0.05 * std::fmax(1.0, jmax))) return 8;
+  }
+  {
+    // the asynchronous host entry: two more frames without waiting, then sync -- the same layer as the synchronous call gives
+    TsdfLayer la(0.10f, 16, 0, 2048), lb(0.10f, 16, 0, 2048);
+    auto ia = TsdfIntegrator::create("merged", cfg, &la), ib = TsdfIntegrator::create("merged", cfg, &lb);
+    for (int i = 0; i < 4; ++i) {
+      T_G_C.t[0] = 0.03f * i;
+      ia->integratePointCloudAsync(T_G_C, points_C, colors, false);
+      ib->integratePointCloud(T_G_C, points_C, colors, false);
+    }
+    ia->waitInputs();
+    ia->sync();
+    LayerMsg ma, mb2;
+    serializeLayerAsMsg(la, false, &ma);
+    serializeLayerAsMsg(lb, false, &mb2);
+    if (ma.blocks.size() != mb2.blocks.size() || ma.blocks.empty()) return 9;
+    for (size_t k = 0; k < ma.blocks.size(); ++k)
+      if (ma.blocks[k].data != mb2.blocks[k].data) return 10;
+    std::printf("asynchronous host entry: %zu blocks identical\n", ma.blocks.size());
+  }
   // recover mode: one mesh block (two triangles seen in frames 0..1) through MeshConverter + processMesh
   MeshMsg mesh;
   mesh.block_edge_length = 1.6f;
