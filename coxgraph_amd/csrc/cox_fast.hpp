@@ -386,7 +386,50 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
     }
     // ---- long lists (the few rays -- a few dozen per frame at 5 cm -- that got their whole walk): ONE WORKGROUP per ray, 512 steps
     // at a time, one step per lane.  (One wave per ray, four steps per lane one after the other, was the pass: 94 us instead of 36.)
-    for (u32 q = blockIdx.x; q < n_long; q += gridDim.x) {
+    // Where the long lists are many (fine voxels: 10^3-10^4 of them) a workgroup each would take them one after the other: there
+    // one WAVE takes a list, up to 256 steps at a time (four independent look-ups per lane in flight), in growing segments for
+    // the lists that stopped early last time.
+    const bool wave_per_list = n_long > 2u * gridDim.x;
+    for (u32 q = wave0; wave_per_list && q < n_long; q += n_waves) {
+      const u32 r = uniform_u32(long_list[q]);
+      const u32 ns = uniform_u32(list_len[r]);
+      if (ns <= kFastShortMax) continue;
+      const u32 off = uniform_u32(V.voff[r]);
+      const u32 old = fast_ld(&reach[r]);
+      u32 carry = 0, stop = ns;
+      u32 base = 0, seg = (old >= 48u) ? 256u : 16u;
+      while (base < ns && stop == ns) {
+        const u32 len = uniform_u32(min(seg, ns - base));
+        bool coll[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 t = 64u * j + lane;
+          coll[j] = (t < len) && fast_collision(V, reach, table_obs, V.pos_of[off + base + t]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (stop != ns || 64u * j >= len) break;
+          const u32 cnt_in = uniform_u32(min(64u, len - 64u * j));  // lanes of this group that hold a step
+          const u64 m = __ballot(coll[j]);
+          // length of the run of collisions that ends at this lane
+          const u64 zeros_below = ~m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+          const u32 run = zeros_below ? lane - (63u - static_cast<u32>(__clzll(static_cast<long long>(zeros_below)))) : lane + 1u + carry;
+          const u64 hit = __ballot(coll[j] && run > static_cast<u32>(max_collisions));
+          if (hit) stop = base + 64u * j + static_cast<u32>(__ffsll(static_cast<long long>(hit))) - 1u;
+          carry = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(run), static_cast<int>(cnt_in - 1u)));
+        }
+        base += len;
+        seg = (base < 64u) ? 64u - base : 256u;
+      }
+      if (lane == 0) {
+        if (stop == ns && ns < nfull[r]) wants = true;
+        if (stop != old) {
+          __hip_atomic_store(&reach[r], stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          any = true;
+        }
+      }
+    }
+    for (u32 q = blockIdx.x; !wave_per_list && q < n_long; q += gridDim.x) {
       const u32 r = uniform_u32(long_list[q]);
       const u32 ns = uniform_u32(list_len[r]);
       if (ns <= kFastShortMax) continue;  // (uniform) handled with the short ones

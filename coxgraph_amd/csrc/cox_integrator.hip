@@ -2459,6 +2459,10 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
       // round-1 list (more rays per surface patch, longer second-order chains), and a frame that ends so is redone by ONE lane
       // (14 and 4 frames/s): four rounds there -- the extra launches are nothing next to frames of a millisecond and more.
       I->fast.rounds = ((max_steps_per_ray(I) - 1) / 3 + 2 <= kAxisCapSmall) ? 2 : kFastMaxRounds;
+      if (I->fast.rounds > 2) {  // ... and longer lists from the start (measured, frames/s at 2 cm / 1 cm: caps 8,16: 628 / 5; 16,32: 694 / 28; 32,32: - / 104)
+        I->fast.cap0 = ((max_steps_per_ray(I) - 1) / 3 > 200) ? 32u : 16u;
+        I->fast.cap1 = 32u;
+      }
       if (const char* e = std::getenv("COX_FAST_ROUNDS")) I->fast.rounds = std::min(kFastMaxRounds, std::max(2, std::atoi(e)));
       if (const char* e = std::getenv("COX_FAST_GROUPS")) I->fast.relax_groups = static_cast<u32>(std::min(256, std::max(8, std::atoi(e))));
       I->fast.force_sequential = std::getenv("COX_FAST_SEQUENTIAL") && std::atoi(std::getenv("COX_FAST_SEQUENTIAL")) != 0;

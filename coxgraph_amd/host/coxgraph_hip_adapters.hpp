@@ -361,7 +361,8 @@ class RegistrationCostFunction {
     check(cox_reg_set_samples(reg_, idx.empty() ? nullptr : idx.data(), idx.size()), "setSampleIndices");
   }
   // voxgraph's RegistrationCostFunction::Config::jacobian_evaluation_method (kAnalytic is voxgraph's default and what coxgraph's server
-  // runs; kNumeric is its debugging aid: central differences of the residuals, here with a step of 1e-6 per parameter)
+  // runs; kNumeric is its debugging aid: central differences of the residuals, here with a step of 1e-4 per parameter -- the
+  // interpolation inside is float, so a residual carries ~1e-7 of rounding noise and a 1e-6 step would turn it into 0.05 of Jacobian)
   enum class JacobianEvaluationMethod { kAnalytic = 0, kNumeric };
   void setJacobianEvaluationMethod(JacobianEvaluationMethod m) { jacobian_method_ = m; }
   // ceres::CostFunction::Evaluate: parameters = {reference pose (x,y,z,yaw), reading pose}, jacobians row-major N x 4
@@ -378,7 +379,7 @@ class RegistrationCostFunction {
         double p[2][4];
         for (int b2 = 0; b2 < 2; ++b2)
           for (int c = 0; c < 4; ++c) p[b2][c] = parameters[b2][c];
-        const double h = 1e-6;
+        const double h = 1e-4;
         p[blk][k] = parameters[blk][k] + h;
         if (cox_reg_evaluate(reg_, p[0], p[1], nullptr, n, rp.data(), nullptr, nullptr) != COX_OK) return false;
         p[blk][k] = parameters[blk][k] - h;
