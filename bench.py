@@ -46,7 +46,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 KERNELS_OF_CLASS = {
-    "merge": "k_bundle_merge", "apply": "k_block_starts+k_apply_block", "bundle_hash": "fillBuffer+k_bundle_insert+k_bundle_keys+k_bundle_clear",
+    "merge": "k_bundle_merge", "apply": "k_block_starts+k_apply_block", "bundle_hash": "fillBuffer+k_bundle_insert+k_bundle_keys",
     "point_sort": "k_rs_hist/offsets/scatter<11> (points)", "touch_emit": "k_scan_small+k_touch*+k_emit*",
     "record_sort": "k_rs_hist/offsets/scatter<12> (records)", "fast_start": "k_fast_points..k_fast_rays (+ point sort)",
     "fast_visits": "k_fast_visits+visit sort+k_fast_inverse (round 0: 8 candidate steps per ray)", "fast_sweeps": "k_fast_sweep (round 0's relaxation launches)",

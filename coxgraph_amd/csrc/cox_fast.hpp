@@ -272,8 +272,8 @@ __global__ void __launch_bounds__(256) k_fast_inverse(const u32* __restrict__ sk
 // everybody leaves, and the frame is redone by k_fast_sequential -- exact either way, and no host round trip.
 //   short lists (<= 32 steps: every list of round 0, later the lists of the rays that did not get their whole walk): eight lanes
 //     per ray, eight rays per wave, eight steps at a time; the collision flags of a ray are one ballot, its stop a few bit operations
-//   long lists (the rays that got their whole walk): one workgroup per ray, 512 steps tested at once
-constexpr u32 kFastRelaxGroups = 128, kFastRelaxThreads = 512;
+//   long lists (the rays that got their whole walk): one workgroup per ray, 1024 steps tested at once
+constexpr u32 kFastRelaxGroups = 128, kFastRelaxThreads = 1024;  // 2048 waves: one pass over 1.6 * 10^4 short lists without a second trip
 constexpr u32 kFastBarrierPolls = 2000000;  // x ~0.5 us: about a second
 constexpr u32 kFastMaxPasses = 4096;
 typedef FastCtl::Bar FastBarrier;  // arrived: workgroups that have arrived, over all passes (never reset: pass p is complete at groups * (p + 1));
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(kFastRelaxThreads) k_fast_relax(FastVisits V, 
         }
       }
     }
-    // ---- long lists (the few rays -- a few dozen per frame at 5 cm -- that got their whole walk): ONE WORKGROUP per ray, 512 steps
+    // ---- long lists (the few rays -- a few dozen per frame at 5 cm -- that got their whole walk): ONE WORKGROUP per ray, 1024 steps
     // at a time, one step per lane.  (One wave per ray, four steps per lane one after the other, was the pass: 94 us instead of 36.)
     // Where the long lists are many (fine voxels: 10^3-10^4 of them) a workgroup each would take them one after the other: there
     // one WAVE takes a list, up to 256 steps at a time (four independent look-ups per lane in flight), in growing segments for

@@ -196,19 +196,24 @@ __device__ __forceinline__ u32 pow2_above(u32 n) {  // power of two > n (FramePa
 }
 __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams* __restrict__ Pp, FrameParams Pv, int by_value, const u32* __restrict__ n_dev, u64* __restrict__ fh_keys,
                                                        u32* __restrict__ fh_first, u32 fh_mask, u32* __restrict__ pslot, Counters* cnt) {
-  if (by_value && n_dev) {
-    Pv.n_points = min(*n_dev, Pv.n_points);
-    Pv.np2 = pow2_above(Pv.n_points);
-  }
-  if (by_value && blockIdx.x == 0 && threadIdx.x == 0) *Pp = Pv;
+  // (the count is taken into a scalar of its own: writing it into the by-value parameter struct sends the whole struct through
+  // scratch memory -- 42 MB of writes and 11 us per launch, seen in the PMC pass)
   const FrameParams P = by_value ? Pv : *Pp;
+  const u32 n_points = (by_value && n_dev) ? min(*n_dev, P.n_points) : P.n_points;
+  if (by_value && blockIdx.x == 0 && threadIdx.x == 0) {
+    *Pp = Pv;
+    if (n_dev) {
+      Pp->n_points = n_points;
+      Pp->np2 = pow2_above(n_points);
+    }
+  }
   const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 lane = lane_id();
   bool valid = false;
   u64 key = 0;
   u32 seq = kInvalid;
-  if (idx < P.n_points) {
-    seq = mixed_sequence(idx, P.n_points);
+  if (idx < n_points) {
+    seq = mixed_sequence(idx, n_points);
     const F3 p{P.xyz[3 * idx], P.xyz[3 * idx + 1], P.xyz[3 * idx + 2]};
     bool clearing = false;
     valid = point_valid(P, p, &clearing);
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(256) k_bundle_insert(FrameParams* __restrict__
   }
   const u32 got = static_cast<u32>(__shfl(static_cast<int>(sl), static_cast<int>(my_leader), 64));
   const u32 slot = valid ? got : kInvalid;
-  if (idx < P.n_points) pslot[idx] = slot;  // kInvalid for points that are not integrated; indexed by point (coalesced)
+  if (idx < n_points) pslot[idx] = slot;  // kInvalid for points that are not integrated; indexed by point (coalesced)
   const u64 m = __ballot(valid && slot != kInvalid);
   if (lane == 0 && m) atomicAdd(&cnt->shard[(idx >> 6) & 63u][kShValid], static_cast<u32>(__popcll(m)));
 }
@@ -284,17 +289,6 @@ __global__ void __launch_bounds__(256) k_bundle_keys(const FrameParams* __restri
   skey[seq] = k;
   sval[seq] = seq;
 }
-// The frame hash is sized for "every point its own bundle" (6 MB) but a frame fills a few thousand slots: instead of a memset
-// per frame, the slots the frame used are put back to empty once its keys have been read (duplicates write the same words).
-__global__ void __launch_bounds__(256) k_bundle_clear(const FrameParams* __restrict__ Pp, const u32* __restrict__ pslot, u64* __restrict__ fh_keys,
-                                                      u32* __restrict__ fh_first) {
-  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Pp->n_points) return;
-  const u32 slot = pslot[idx];
-  if (slot == kInvalid) return;
-  fh_keys[slot] = kEmptyKey;
-  fh_first[slot] = 0xFFFFFFFFu;
-}
 // the two ping-pong buffers of the bundling sort + where its result ended up
 struct BundleView {
   const u32* key[2];
@@ -313,7 +307,11 @@ __device__ __forceinline__ bool bundle_head(const u32* __restrict__ skey, u32 i,
   const u32 k = skey[i];
   return k != kInvalid && (i == 0 || skey[i - 1] != k);
 }
-__global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ tile_sums) {
+// The frame hash is sized for "every point its own bundle" (6 MB) but a frame fills a few thousand slots: instead of a memset
+// per frame, the slots the frame used are put back to empty once its keys have been read (duplicates write the same words) --
+// here, behind the bundling sort (round 2 had a launch of its own for it right behind k_bundle_keys).
+__global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restrict__ Pp, BundleView V, u32* __restrict__ tile_sums, const u32* __restrict__ pslot,
+                                                      u64* __restrict__ fh_keys, u32* __restrict__ fh_first, int self_clean) {
   __shared__ u32 lds[4];
   const u32 n = Pp->n_points;
   const u32* __restrict__ skey = V.key[V.info->parity & 1u];
@@ -321,7 +319,17 @@ __global__ void __launch_bounds__(256) k_bundle_count(const FrameParams* __restr
   for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     u32 c = 0;
 #pragma unroll
-    for (u32 q = 0; q < kBoundTile / 256; ++q) c += bundle_head(skey, tile * kBoundTile + q * 256 + threadIdx.x, n) ? 1u : 0u;
+    for (u32 q = 0; q < kBoundTile / 256; ++q) {
+      const u32 i = tile * kBoundTile + q * 256 + threadIdx.x;
+      c += bundle_head(skey, i, n) ? 1u : 0u;
+      if (self_clean && i < n) {
+        const u32 slot = pslot[i];
+        if (slot != kInvalid) {
+          fh_keys[slot] = kEmptyKey;
+          fh_first[slot] = 0xFFFFFFFFu;
+        }
+      }
+    }
     u32 tot;
     (void)block_exclusive_scan<4>(c, &tot, lds);
     if (threadIdx.x == 0) tile_sums[tile] = tot;
@@ -1727,13 +1735,13 @@ static int stage_hash(const StageCtx& c, hipStream_t s) {
     {
       TimedRegion t(I, COX_KC_BUNDLE_HASH, s);
       // with anti-grazing the hash is read again by touch / emit (stage B1), after this frame's pslot may have been reused:
-      // that (rare) configuration keeps the memset; otherwise the frame cleans up after itself (k_bundle_clear)
+      // that (rare) configuration keeps the memset; otherwise the frame cleans up after itself (in k_bundle_count, stage M)
       const bool self_clean = !I->cfg.enable_anti_grazing;
       if (!self_clean) COX_HIP(hipMemsetAsync(F.fh_keys, 0xFF, sizeof(u64) * I->fh_cap + sizeof(u32) * I->fh_cap, s));
       hipLaunchKernelGGL(k_bundle_insert, grid_for(n), dim3(256), 0, s, F.d_params, I->h_params[c.slot], by_value ? 1 : 0, c.n_dev, F.fh_keys, F.fh_first,
                          I->fh_cap - 1, B.pslot, F.cnt);
       hipLaunchKernelGGL(k_bundle_keys, grid_for(n), dim3(256), 0, s, F.d_params, F.fh_keys, F.fh_first, B.pslot, B.skey[0], B.sval[0], B.sort_info);
-      if (self_clean) hipLaunchKernelGGL(k_bundle_clear, grid_for(n), dim3(256), 0, s, F.d_params, B.pslot, F.fh_keys, F.fh_first);
+      (void)self_clean;  // (the frame cleans its hash up in k_bundle_count, stage M)
     }
   }
   return COX_OK;
@@ -1759,7 +1767,7 @@ static int stage_merge(const StageCtx& c, hipStream_t s) {
     BundleView V{{B.skey[0], B.skey[1]}, {B.sval[0], B.sval[1]}, B.sort_info};
     // bundle boundaries: heads per tile, then the starts
     const dim3 gt(std::max<u32>(1, (n + kBoundTile - 1) / kBoundTile));
-    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head);
+    hipLaunchKernelGGL(k_bundle_count, gt, dim3(256), 0, s, F.d_params, V, B.head, B.pslot, F.fh_keys, F.fh_first, I->cfg.enable_anti_grazing ? 0 : 1);
     hipLaunchKernelGGL(k_bundle_starts, gt, dim3(256), 0, s, F.d_params, V, B.head, B.bstart, F.cnt);
     {
       TimedRegion t(I, COX_KC_MERGE, s);
