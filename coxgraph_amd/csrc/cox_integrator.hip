@@ -1111,6 +1111,18 @@ __global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ 
   }
 }
 
+// ---- host inputs: pinned host memory read by a kernel ------------------------------------------------------------------------
+// An experiment (COX_H2D=kernel), not the default: hipMemcpyAsync hands a pinned-to-device copy to the SDMA engine and pays two
+// engine hand-overs per copy on the frame's stream; pinned host memory is mapped into the device's address space, so an ordinary
+// kernel can read it instead (16 B per lane, grid-stride).  Measured erratic: faster for `merged`, much slower for `fast`.
+typedef u32 U32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy_from_host(U32x4* __restrict__ dst, const U32x4* __restrict__ src, size_t n16, u32* __restrict__ dst_tail,
+                                                        const u32* __restrict__ src_tail, u32 n_tail_words) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(&src[i]);
+  if (blockIdx.x == 0 && threadIdx.x < n_tail_words) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 // ---- self-test: the hoisted-reciprocal division of k_bundle_merge against the compiler's IEEE '/' -----------------
 __global__ void __launch_bounds__(256) k_selftest_division(u64 n, u64 seed, u32* __restrict__ mismatches) {
   u64 bad = 0;
@@ -2697,14 +2709,30 @@ int cox_integrate_points_ex(cox_integrator_t* I, const float T_G_C[7], const flo
 // Host buffers -> staging set k of the frame about to be enqueued, on that frame's ray-generation stream, without waiting for
 // anything but the staging set itself.  Pageable memory goes through a pinned bounce buffer (one CPU copy; the caller's buffer is
 // free again when the call returns), pinned memory is copied from directly.
-static bool host_pointer_is_pinned(const void* p) {
+// -> the address the device reads the buffer at (pinned memory is mapped), nullptr for pageable memory
+static const void* host_pointer_device_view(const void* p) {
   hipPointerAttribute_t a;
   const hipError_t e = hipPointerGetAttributes(&a, p);
   if (e != hipSuccess) {
     (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime
-    return false;
+    return nullptr;
   }
-  return a.type == hipMemoryTypeHost;
+  if (a.type != hipMemoryTypeHost) return nullptr;
+  return a.devicePointer ? a.devicePointer : p;
+}
+// bytes (a multiple of 4) from pinned host memory, seen by the device at src_dev, to dst on stream s
+static int copy_pinned_to_device(void* dst, const void* src_host, const void* src_dev, size_t bytes, hipStream_t s) {
+  // (COX_H2D=kernel selects it; not the default: merged 3.0 k -> 3.8 k frames/s from pinned clouds in one run, fast 2.1 k -> 0.8 k in the same run)
+  static const bool use_kernel = std::getenv("COX_H2D") && std::string(std::getenv("COX_H2D")) == "kernel";
+  if (!use_kernel || (reinterpret_cast<uintptr_t>(src_dev) & 15u) || (reinterpret_cast<uintptr_t>(dst) & 15u) || (bytes & 3u)) {
+    COX_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, s));
+    return COX_OK;
+  }
+  const size_t n16 = bytes / 16;
+  const u32 tail_words = static_cast<u32>((bytes - 16 * n16) / 4);
+  hipLaunchKernelGGL(k_copy_from_host, dim3(1024), dim3(256), 0, s, static_cast<U32x4*>(dst), static_cast<const U32x4*>(src_dev), n16,
+                     reinterpret_cast<u32*>(static_cast<char*>(dst) + 16 * n16), reinterpret_cast<const u32*>(static_cast<const char*>(src_dev) + 16 * n16), tail_words);
+  return COX_OK;
 }
 // the stream the next frame's first stage will run on
 static inline hipStream_t next_input_stream(const cox_integrator* I) { return stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets)); }
@@ -2714,7 +2742,9 @@ static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_b
   // the staging set is free once the frame that used it three frames ago has read it for the last time; that frame's stages
   // H .. M are enqueued by the caller's thread, so the event is recorded by now
   if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s_in, I->in_free[k], 0));
-  const bool pinned = host_pointer_is_pinned(a) && (!b || host_pointer_is_pinned(b));
+  const void* dev_a = host_pointer_device_view(a);
+  const void* dev_b = b ? host_pointer_device_view(b) : nullptr;
+  const bool pinned = dev_a != nullptr && (!b || dev_b != nullptr);
   const void* src_a = a;
   const void* src_b = b;
   if (!pinned) {
@@ -2740,9 +2770,16 @@ static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_b
     if (b) memcpy(I->pin_rgba[k], b, b_bytes * n);
     src_a = I->pin_xyz[k];
     src_b = b ? I->pin_rgba[k] : nullptr;
+    dev_a = host_pointer_device_view(src_a);
+    dev_b = b ? host_pointer_device_view(src_b) : nullptr;
   }
-  COX_HIP(hipMemcpyAsync(dst_a, src_a, a_bytes * n, hipMemcpyHostToDevice, s_in));
-  if (b) COX_HIP(hipMemcpyAsync(dst_b, src_b, b_bytes * n, hipMemcpyHostToDevice, s_in));
+  if (dev_a && (!b || dev_b)) {
+    COX_TRY(copy_pinned_to_device(dst_a, src_a, dev_a, a_bytes * n, s_in));
+    if (b) COX_TRY(copy_pinned_to_device(dst_b, src_b, dev_b, b_bytes * n, s_in));
+  } else {
+    COX_HIP(hipMemcpyAsync(dst_a, src_a, a_bytes * n, hipMemcpyHostToDevice, s_in));
+    if (b) COX_HIP(hipMemcpyAsync(dst_b, src_b, b_bytes * n, hipMemcpyHostToDevice, s_in));
+  }
   COX_HIP(hipEventRecord(I->in_ready[k], s_in));
   I->in_used[k] = true;
   in->ready = nullptr;  // (same stream as the frame's first stage: stream order)

@@ -67,3 +67,30 @@ def test_synthetic_scene_is_deterministic_and_plausible():
     assert abs(depth[245, 323] - 1.25) < 5e-3
     # the corners see the front wall x = 4, 3 m ahead (z-depth, not range)
     assert abs(depth[0, 0] - 3.0) < 1e-5
+
+
+def test_runtime_prepare_is_explicit_and_loading_the_library_has_no_side_effect():
+    """the library must not touch the process environment when it is loaded; cox_runtime_prepare() is the explicit way to
+    ask for 16 hardware queues, and it leaves a value the host has chosen alone.  Run in a fresh interpreter (the package's own
+    __init__ sets the variable for Python hosts, on purpose)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "coxgraph_amd", "lib", "libcoxgraph_hip.so")
+    code = (
+        "import ctypes, os\n"
+        "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+        f"lib = ctypes.CDLL({lib!r})\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.getenv.restype = ctypes.c_char_p\n"
+        "assert libc.getenv(b'GPU_MAX_HW_QUEUES') is None, 'loading the library changed the environment'\n"
+        "assert lib.cox_runtime_prepare() == 1\n"
+        "assert libc.getenv(b'GPU_MAX_HW_QUEUES') == b'16'\n"
+        "assert lib.cox_runtime_prepare() == 0  # already set: the value stands\n"
+        "libc.setenv(b'GPU_MAX_HW_QUEUES', b'7', 1)\n"
+        "assert lib.cox_runtime_prepare() == 0 and libc.getenv(b'GPU_MAX_HW_QUEUES') == b'7'\n"
+        "f = lib.cox_status_string\n"
+        "f.restype = ctypes.c_char_p\n"
+        "assert f(-9) == b'COX_ERR_COMM'\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
