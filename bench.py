@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--other-config-frames", type=int, default=24, help="timed frames of each `other_configs` block (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the CPU baseline sample (0 = skip); ~10 s of CPU work at the default")
     ap.add_argument("--reg-iters", type=int, default=50)
-    ap.add_argument("--pcie-frames", type=int, default=100, help="frames of the PCIe-inclusive legs (0 = skip)")
+    ap.add_argument("--pcie-frames", type=int, default=-1, help="timed frames of the PCIe-inclusive legs (default: as many as --steps; 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--serial", action="store_true", help="sync after every frame (profiling aid: kernel times without cross-frame overlap)")
     ap.add_argument("--no-ramp", action="store_true", help="no untimed clock-ramp frames (PMC passes: every dispatch of the run then belongs to warmup + steps frames)")
@@ -173,7 +173,7 @@ def main():
     if (W, H) not in synth.INTRINSICS:
         raise SystemExit(f"bench.py: no intrinsics for {W}x{H} (have {sorted(synth.INTRINSICS)})")
     n_frames = args.warmup + args.steps
-    keep_host = max(args.cpu_frames, args.pcie_frames, 1)
+    keep_host = max(args.cpu_frames, (args.warmup + args.steps) if args.pcie_frames < 0 else (args.warmup + args.pcie_frames if args.pcie_frames else 0), 1)
 
     def make_frames(n, w, h, keep):
         """-> (host frames (the first `keep`), device-resident frames)"""
@@ -384,76 +384,88 @@ def main():
                 other_configs[name] = {"error": str(e)}
 
     # ---- PCIe-inclusive: what the boundary costs when the caller hands over host buffers -----------------------------------
+    # Every leg repeats the resident run with another entry point: the same frames (warm-up, then `steps` timed), a fresh layer, the
+    # clock ramp; `--pcie-frames` bounds the timed frames (default: all of them).
     pcie = None
-    if rank == 0 and world == 1 and args.pcie_frames > 0:
-        nf = min(args.pcie_frames, len(host_frames))
-        pcie = {"frames": nf, "bytes_per_frame_points": int(host_frames[0][1].nbytes + host_frames[0][2].nbytes),
+    if rank == 0 and world == 1 and args.pcie_frames != 0:
+        nw = min(args.warmup, len(host_frames))
+        nf = min(args.steps if args.pcie_frames < 0 else min(args.pcie_frames, args.steps), len(host_frames) - nw)
+        pcie = {"frames": nf, "warmup": nw, "bytes_per_frame_points": int(host_frames[0][1].nbytes + host_frames[0][2].nbytes),
                 "bytes_per_frame_depth": int(host_frames[0][3].nbytes + W * H * 4),
-                "note": "never `value`.  host points: cox_integrate_points_async (the reference's boundary, tsdf_recover.h:71-77: host buffers; H2D on the engine's "
-                        "input stream beside the kernels of earlier frames) from pinned and from pageable memory (pageable: one CPU copy into a pinned bounce buffer), "
-                        "and the synchronous cox_integrate_points; depth: pinned depth + colour images copied on the caller's stream, cox_integrate_depth_dev (point "
-                        "count stays on the device)"}
+                "note": "never `value`.  The same frames as the resident run through the host entry points, frames in flight: cox_integrate_points_async (the "
+                        "reference's boundary, tsdf_recover.h:71-77: host point clouds) from pinned and from pageable memory (pageable: one CPU copy into a "
+                        "pinned bounce buffer), copied by the copy engine on the integrator's input stream; cox_integrate_depth_async (pinned depth + colour "
+                        "images, converted on the device, the point count stays there); device images the caller copies on a stream of its own "
+                        "(cox_integrate_depth_dev); and the synchronous cox_integrate_points, one frame in flight"}
         K = np.array(synth.INTRINSICS[(W, H)], np.float32)
+        rgba_img = torch.from_numpy(synth.frame_colors(W, H)).pin_memory()
+
+        def timed_leg(method, call, frames, sync_each=False):
+            """every buffer once untimed on a scratch layer (a pinned buffer's first DMA pays for its mappings; a sensor driver reuses a ring of
+            them), then warm-up + timed frames on a fresh layer like run_stream"""
+            scratch = Integrator(eng, Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768), cfg, method)
+            for f in frames[:nw + nf]:
+                call(scratch, f)
+            scratch.sync()
+            del scratch
+            integ = Integrator(eng, Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768), cfg, method)
+            clock_ramp(method, dev_frames, cfg, args.voxel)
+            for f in frames[:nw]:
+                call(integ, f)
+            integ.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in frames[nw:nw + nf]:
+                call(integ, f)
+                if sync_each:
+                    integ.sync()
+            integ.sync()
+            torch.cuda.synchronize()
+            return nf / (time.perf_counter() - t0)
+
         for m in (["merged", "fast"] if args.method in ("merged", "fast") else [args.method]):
             res = {}
-            pinned = [(T, torch.from_numpy(p).pin_memory(), torch.from_numpy(c).pin_memory()) for T, p, c, _ in host_frames[:nf]]
-            for label, src in (("host_points_pinned_frames_per_s", pinned), ("host_points_pageable_frames_per_s", [(T, torch.from_numpy(p), torch.from_numpy(c)) for T, p, c, _ in host_frames[:nf]])):
-                lp = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-                ip = Integrator(eng, lp, cfg, m)
-                for T, x, c in src:  # untimed: every buffer once (a pinned buffer's first DMA pays for its mappings; a sensor driver reuses a ring of them)
-                    ip.integrate_points_async(T, x.data_ptr(), c.data_ptr(), x.shape[0])
-                ip.sync()
-                ip2 = Integrator(eng, Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768), cfg, m)
-                del ip
-                ip = ip2
-                t0 = time.perf_counter()
-                for T, x, c in src:
-                    ip.integrate_points_async(T, x.data_ptr(), c.data_ptr(), x.shape[0])
-                ip.sync()
-                res[label] = nf / (time.perf_counter() - t0)
-                del ip, lp
-            lp = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-            ip = Integrator(eng, lp, cfg, m)
-            nsync = min(nf, 30)
-            for T, p, c, _ in host_frames[:3]:
-                ip.integrate_points(T, p, c)
+            pinned = [(T, torch.from_numpy(p).pin_memory(), torch.from_numpy(c).pin_memory()) for T, p, c, _ in host_frames[:nw + nf]]
+            pageable = [(T, torch.from_numpy(p), torch.from_numpy(c)) for T, p, c, _ in host_frames[:nw + nf]]
+            by_address = lambda I, f: I.integrate_points_async(f[0], f[1].data_ptr(), f[2].data_ptr(), f[1].shape[0])
+            res["host_points_pinned_frames_per_s"] = timed_leg(m, by_address, pinned)
+            res["host_points_pageable_frames_per_s"] = timed_leg(m, by_address, pageable)
+            del pinned, pageable
+            ns = min(nf, 30)
+            sync_frames = host_frames[:nw + nf]
+            lp = Integrator(eng, Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768), cfg, m)
+            for T, p, c, _ in sync_frames[:3]:
+                lp.integrate_points(T, p, c)
             t0 = time.perf_counter()
-            for T, p, c, _ in host_frames[:nsync]:
-                ip.integrate_points(T, p, c)  # cox_integrate_points: H2D + frame + sync, one frame in flight
-            res["host_points_synchronous_frames_per_s"] = nsync / (time.perf_counter() - t0)
-            del ip, lp
-            # depth images (1.2 MB + 1.2 MB colour) from pinned host memory through cox_integrate_depth_async (copied and converted on the
-            # frame's own ray-generation stream; the point count never visits the host) ...
-            rgba_img = torch.from_numpy(synth.frame_colors(W, H)).pin_memory()
-            pinned_d = [torch.from_numpy(d).pin_memory() for _, _, _, d in host_frames[:nf]]
-            ld = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-            idp = Integrator(eng, ld, cfg, m)
-            for (T, _, _, _), hd in zip(host_frames[:nf], pinned_d):  # untimed: every pinned image once
-                idp.integrate_depth_async(T, hd.data_ptr(), rgba_img.data_ptr(), W, H, K)
-            idp.sync()
-            t0 = time.perf_counter()
-            for (T, _, _, _), hd in zip(host_frames[:nf], pinned_d):
-                idp.integrate_depth_async(T, hd.data_ptr(), rgba_img.data_ptr(), W, H, K)
-            idp.sync()
-            res["depth_image_frames_per_s"] = nf / (time.perf_counter() - t0)
-            del idp, ld
-            # ... and as device images the caller copies on a stream of its own, ordered against the engine (cox_integrator_set_input_stream)
-            ld = Layer(eng, args.voxel, device=local_rank, capacity_blocks=32768)
-            idp = Integrator(eng, ld, cfg, m)
-            side = torch.cuda.Stream()
-            idp.set_input_stream(side.cuda_stream)
-            with torch.cuda.stream(side):
-                for (T, _, _, _), hd in zip(host_frames[:5], pinned_d[:5]):  # untimed: first launches of the depth kernels, allocator warm-up
-                    idp.integrate_depth_dev(T, hd.to("cuda", non_blocking=True).data_ptr(), rgba_img.to("cuda", non_blocking=True).data_ptr(), W, H, K)
-                idp.sync()
-                t0 = time.perf_counter()
-                for (T, _, _, _), hd in zip(host_frames[:nf], pinned_d):
-                    dd = hd.to("cuda", non_blocking=True)
-                    cc = rgba_img.to("cuda", non_blocking=True)
-                    idp.integrate_depth_dev(T, dd.data_ptr(), cc.data_ptr(), W, H, K)
-                idp.sync()
-                res["depth_image_on_caller_stream_frames_per_s"] = nf / (time.perf_counter() - t0)
-            del idp, ld, pinned, pinned_d
+            for T, p, c, _ in sync_frames[3:3 + ns]:
+                lp.integrate_points(T, p, c)  # cox_integrate_points: H2D + frame + sync, one frame in flight
+            res["host_points_synchronous_frames_per_s"] = ns / (time.perf_counter() - t0)
+            del lp
+            # depth images (1.2 MB + 1.2 MB colour) from pinned host memory through cox_integrate_depth_async ...
+            pinned_d = [(T, torch.from_numpy(d).pin_memory()) for T, _, _, d in host_frames[:nw + nf]]
+            res["depth_image_frames_per_s"] = timed_leg(m, lambda I, f: I.integrate_depth_async(f[0], f[1].data_ptr(), rgba_img.data_ptr(), W, H, K), pinned_d)
+            # ... and as device images the caller copies on a stream of its own, ordered against the engine (cox_integrator_set_input_stream).
+            # (ONE stream made with hipStreamCreateWithFlags, as a host program has: the first torch.cuda.Stream() creates a pool of 64, and
+            # hardware queues shared between streams are what DESIGN.md section 5 is about)
+            import ctypes
+            raw = ctypes.c_void_p()
+            if ctypes.CDLL("libamdhip64.so").hipStreamCreateWithFlags(ctypes.byref(raw), 1) != 0:
+                raise SystemExit("bench.py: hipStreamCreateWithFlags failed")
+            side = torch.cuda.ExternalStream(raw.value)
+            ring = [(torch.empty(W * H, dtype=torch.float32, device="cuda"), torch.empty(W * H * 4, dtype=torch.uint8, device="cuda")) for _ in range(8)]
+            turn = [0]
+
+            def on_caller_stream(I, f):
+                dd, cc = ring[turn[0] % len(ring)]  # (the engine orders the caller's stream behind its last read of the images)
+                turn[0] += 1
+                I.set_input_stream(side.cuda_stream)
+                with torch.cuda.stream(side):
+                    dd.copy_(f[1].view(-1), non_blocking=True)
+                    cc.copy_(rgba_img.view(-1), non_blocking=True)
+                I.integrate_depth_dev(f[0], dd.data_ptr(), cc.data_ptr(), W, H, K)
+            res["depth_image_on_caller_stream_frames_per_s"] = timed_leg(m, on_caller_stream, pinned_d)
+            torch.cuda.synchronize()
+            del pinned_d, ring  # (the stream is left to the process: torch keeps a reference to it)
             resident = fps if m == args.method else ((other or {}).get(m, {}).get("value"))
             if resident:
                 res["resident_frames_per_s"] = resident

@@ -318,6 +318,12 @@ class Integrator:
         return dict(sequential_frames=int(out[0]), round1_frames=int(out[1]), passes_round0=int(out[2]), passes_later_rounds=int(out[3]),
                     frames=int(out[4]), sequential_frames_list_outgrown=int(out[5]), sequential_frames_barrier_gave_up=int(out[6]), frames_with_three_rounds_or_more=int(out[7]), relax_work_ns=int(out[8]), relax_barrier_wait_ns=int(out[9]))
 
+    def update_stats(self):
+        """last frame: tiles whose classification was split over the chip, and their chunks (cox_integrator_update_stats)."""
+        out = (C.c_uint64 * 2)()
+        self.eng.check(self.eng.fn("integrator_update_stats")(self.h, out), "integrator_update_stats")
+        return dict(split_tiles=int(out[0]), chunks=int(out[1]))
+
     def host_time(self, reset=False):
         """(ms, frames): host time spent inside the integrate calls (enqueueing; cox_integrator_host_time)."""
         ms, n = C.c_double(), C.c_uint64()

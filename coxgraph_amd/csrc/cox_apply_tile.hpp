@@ -145,9 +145,104 @@ __device__ __forceinline__ float sdf_of_record(const FrameParams& P, const RayOf
     return compute_sdf(P, y.a, gx, gy, gz);
 }
 
+// ---- large tiles: phase 1 by the whole chip ------------------------------------------------------------------------------------
+// The rays of a frame all leave from the sensor: the tiles around it are crossed by every ray (1 cm: 2 * 10^6 of the frame's 2.5 * 10^7
+// records in ONE tile), and k_apply_block gives a tile to one workgroup -- its duration was that tile's, 0.8 ms, whatever the other
+// 10^5 tiles cost (which is why neither larger tiles nor a wave per small tile changed it).  Phase 1 is a sum: saturating weights and
+// record counts per voxel, exact in any order.  So the tiles of more than two chunks (of kBigChunk records) are cut into chunks,
+// every chunk is classified by a workgroup of its own into LDS and added to the tile's accumulators in global memory (integer
+// atomics), and k_apply_block starts such a tile from those instead of running over its records.  Phases 2-4 are unchanged -- a voxel
+// whose records did not all fold is replayed in order by the one workgroup, from the records, as before (the tiles around the sensor are
+// free space: nothing to replay).
+constexpr u32 kBigChunk = 4096, kBigChunkMin = 1024;  // (COX_BIG_CHUNK: the chunk, at least kBigChunkMin; tiles of more than two chunks are split)
+constexpr u32 kBigCap = 8192;  // large tiles a frame may split; further ones are taken whole
+struct BigTiles {
+  u32* of_tile;   // [tiles] slot + 1 of a split tile, 0 otherwise; zero between frames
+  u32* acc;       // [kBigCap][2][256] sum of saturating weights, count | dirty << 31; zero between frames
+  uint2* chunks;  // (tile, first record)
+  u32 chunk_cap;
+  u32 chunk;      // records per chunk; tiles of more than 2 * chunk records are split
+};
+__global__ void __launch_bounds__(256) k_big_tiles(const u32* __restrict__ tile_beg, const u32* __restrict__ tile_end, const int4* __restrict__ ord_info, Counters* cnt,
+                                                   BigTiles B) {
+  const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTilesPerBlock;
+  for (u32 tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_tiles; tile += gridDim.x * blockDim.x) {
+    const u32 beg = tile_beg[tile], end = tile_end[tile];
+    if (end <= beg || end - beg <= 2u * B.chunk) continue;
+    if (static_cast<u32>(ord_info[tile >> kSlabBits].w) == kInvalid) continue;  // (k_apply_block skips such a tile: nobody would take the slot back)
+    const u32 slot = atomicAdd(&cnt->n_big_tiles, 1u);
+    if (slot >= kBigCap) continue;
+    const u32 nch = (end - beg + B.chunk - 1u) / B.chunk;
+    const u32 base = atomicAdd(&cnt->n_big_chunks, nch);
+    const bool fits = base + nch <= B.chunk_cap;  // (always: the list holds records / kBigChunkMin + kBigCap entries)
+    if (fits) B.of_tile[tile] = slot + 1u;
+    for (u32 c = 0; c < nch && base + c < B.chunk_cap; ++c) B.chunks[base + c] = make_uint2(fits ? tile : kInvalid, beg + c * B.chunk);
+  }
+}
+template <bool kQ>
+__global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_big_classify(const FrameParams* __restrict__ Pp, RayArrays R, const int4* __restrict__ ord_info, RecordView V,
+                                                                                                   const u32* __restrict__ tile_end, const Counters* cnt, BigTiles B) {
+  const FrameParams P = *Pp;
+  __shared__ u32 acc_sum[kTileVox], acc_cnt[kTileVox];
+  const u32 n_chunks = min(cnt->n_big_chunks, B.chunk_cap);
+  const u32 par = V.info->parity & 1u;
+  const u32* __restrict__ rec_key = V.key[par];
+  const u32* __restrict__ rec_ray = V.ray[par];
+  const u32 tid = threadIdx.x;
+  for (u32 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const uint2 c = B.chunks[ch];
+    const u32 tile = c.x;
+    if (tile == kInvalid) continue;  // (uniform)
+    const int4 info = ord_info[tile >> kSlabBits];
+    const u32 beg = c.y, end = min(tile_end[tile], beg + B.chunk);
+    const int gz = info.z + static_cast<int>(tile & (kTilesPerBlock - 1u));
+    __syncthreads();  // the previous chunk's sums have been handed over
+    if (tid < kTileVox) {
+      acc_sum[tid] = 0;
+      acc_cnt[tid] = 0;
+    }
+    __syncthreads();
+    for (u32 i0 = beg + tid; i0 < end; i0 += 2 * kBT) {  // (k_apply_block's phase 1)
+      const u32 i1 = i0 + kBT;
+      const bool has1 = i1 < end;
+      const u32 k0 = rec_key[i0], r0 = rec_ray[i0];
+      const u32 k1 = has1 ? rec_key[i1] : 0u, r1 = has1 ? rec_ray[i1] : r0;
+      const RayOfRecord y0 = ray_of_record<kQ>(R, r0), y1 = ray_of_record<kQ>(R, r1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !has1) break;
+        const u32 lin = (u ? k1 : k0) & (kTileVox - 1u);
+        const RayOfRecord& y = u ? y1 : y0;
+        const float sdf = sdf_of_record<kQ>(P, y, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+        const float uw = update_weight(P, sdf, y.w);
+        bool fold = foldable_update(P, sdf, uw);
+        if (fold && atomicAdd(&acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;
+        atomicAdd(&acc_cnt[lin], 1u);
+        if (!fold) atomicOr(&acc_cnt[lin], 0x80000000u);
+      }
+    }
+    __syncthreads();
+    if (tid < kTileVox) {
+      const u32 cv = acc_cnt[tid];
+      if (cv) {
+        u32* g = B.acc + static_cast<size_t>(B.of_tile[tile] - 1u) * (2u * kTileVox);
+        const u32 sv = acc_sum[tid];
+        const u32 old = sv ? atomicAdd(&g[tid], sv) : 0u;
+        const bool over = old + sv < old || old + sv >= (1u << 30);  // the tile's sum must stay an exact u32 below 2^30: else the voxel is replayed
+        atomicAdd(&g[kTileVox + tid], cv & 0x7FFFFFFFu);
+        if ((cv >> 31) || over) atomicOr(&g[kTileVox + tid], 0x80000000u);
+      }
+    }
+  }
+}
+
 template <bool kQ, u32 kTS, bool kBucket>
 __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_apply_block(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
-                                                     u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks) {
+                                                     u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err, u32* __restrict__ h_nblocks,
+                                                     u32 min_records, BigTiles big) {
+  // big.of_tile != nullptr (tiles, not buckets): a tile with a slot there was classified by k_big_classify; phase 1 is its accumulators.
+  // min_records > 0 (tiles, not buckets): only the tiles with at least that many records; the others are left, ranges and all, to
+  // k_apply_wave behind this kernel.
   // kTS = log2(voxels per tile): 8 = one z slab of the block (16 tiles per block), 9 = two (fine voxels: half as many tiles,
   // each a chain of dependent round trips, and thread = voxel uses all 512 threads)
   constexpr u32 kTV = 1u << kTS, kTPB = 4096u >> kTS, kSlabs = kTV / 256u;
@@ -179,6 +274,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
   for (u32 unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     const u32 beg = tile_beg[unit], end = tile_end[unit];
     if (end <= beg) continue;  // (uniform) no record touches this slab of the block
+    if (!kBucket && end - beg < min_records) continue;  // (uniform) a small tile: k_apply_wave's
    for (u32 tile = unit; tile < n_tiles; tile += (kBucket ? 4096u : n_tiles)) {
     __syncthreads();           // everybody has read its range and is done with the previous tile's LDS
     if (tid == 0) {
@@ -193,13 +289,25 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int gz0 = info.z + static_cast<int>((tile & (kTPB - 1u)) * kSlabs);  // first z slab of the tile
     u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTPB - 1u)) * kTV) * kWordsPerVoxel;
     for (u32 i = tid; i < kTV * kWordsPerVoxel; i += kBT) blk[i] = gblk[i];
-    for (u32 v = tid; v < kTV; v += kBT) {
-      acc_sum[v] = 0;
-      acc_cnt[v] = 0;
+    const u32 split = (!kBucket && kTS == kTileShift && big.of_tile) ? big.of_tile[tile] : 0u;  // (uniform)
+    if (split) {
+      u32* g = big.acc + static_cast<size_t>(split - 1u) * (2u * kTV);
+      for (u32 v = tid; v < kTV; v += kBT) {
+        acc_sum[v] = g[v];
+        acc_cnt[v] = g[kTV + v];
+        g[v] = 0;  // leave the accumulators empty for the next frame
+        g[kTV + v] = 0;
+      }
+    } else {
+      for (u32 v = tid; v < kTV; v += kBT) {
+        acc_sum[v] = 0;
+        acc_cnt[v] = 0;
+      }
     }
     __syncthreads();
+    if (split && tid == 0) big.of_tile[tile] = 0;  // (behind the barrier: every thread has read the slot) ... and the slot table
     // ---- 1. classify --------------------------------------------------------------------------------------------------
-    for (u32 i0 = beg + tid; i0 < end; i0 += 2 * kBT) {  // two records per thread in flight: the gathers are latency-bound
+    for (u32 i0 = beg + tid; i0 < (split ? beg : end); i0 += 2 * kBT) {  // two records per thread in flight: the gathers are latency-bound
       const u32 i1 = i0 + kBT;
       const bool has1 = i1 < end;
       const u32 k0 = rec_key[i0], r0 = rec_ray[i0];
@@ -312,6 +420,263 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
   if (lane == 0 && my_voxels) {
     u32* sh = cnt->shard[(blockIdx.x * kBW + wave) & 63u];
+    atomicAdd(&sh[kShUpdates], my_updates);
+    atomicAdd(&sh[kShVoxels], my_voxels);
+    atomicMax(&sh[kShMaxRun], my_maxrun);
+  }
+}
+
+// ---- wave apply: k_apply_block's four phases, ONE WAVE per small tile (fine voxels) ---------------------------------------------
+// At fine voxels a frame has ~10^5 tiles of a few hundred records each (1 cm: 2.5 * 10^7 records over 10^5 tiles), and a tile is a
+// chain of dependent global round trips -- range -> block info -> voxels, records -> ray lines -> (hard voxels) records again -> ray
+// lines, colours -- with a workgroup barrier between the phases.  With a 512-thread workgroup per tile a CU has FOUR tiles in flight and
+// half the lanes of phase 1 have no record; the kernel is bound by that chain (0.8 ms at 1 cm for ~0.1 ms worth of instructions and
+// 0.04 ms worth of bytes).  A first wave-per-tile kernel that kept k_apply_block's loops (64 records per round, phase 3 re-reading keys,
+// rays, lines and colours round by round) was no faster: sixteen tiles in flight per CU, but three times the round trips per tile.
+// This one is built around the round trips instead.  A wave owns a tile of at most kN records (larger tiles go to k_apply_block, which
+// runs first: the tiles next to the camera hold 10^4 records and more):
+//   T1  range and block info of the NEXT tile, fetched while this one is worked on;
+//   T2  the tile's voxels (four per lane, in registers) and ALL its records (kN / 64 per lane), issued together;
+//   T3  the rays' 32-B lines (point_G - origin, length, weight, colour: written by the merge), all of them together;
+//       then every record is evaluated once and KEPT in LDS (voxel, sdf, update weight, colour) -- phases 2 and 3 never go back to
+//       global memory: fold (thread = voxel), stable counting sort of the hard voxels' records by voxel, ordered replay;
+//   T4  the tile goes back (nothing waits for it).
+// No workgroup barrier anywhere (LDS traffic of one wave is in order).  Same operations on the same values in the same order per voxel
+// as k_apply_block: bit-identical.  The blocks of the frame are dealt to the XCDs by ordinal (block ordinal mod 8 = XCD of the
+// workgroup): the sixteen tiles of a block, which share their rays' lines, stay in one L2.
+constexpr u32 kWaveTileWaves = 4;   // waves (= tiles in flight) per workgroup
+template <u32 kN>
+struct alignas(16) WaveTileLds {
+  u32 acc_sum[kTileVox];
+  u32 acc_cnt[kTileVox];
+  u32 hardbits[kTileVox / 32];
+  float r_sdf[kN], r_uw[kN];
+  u32 r_col[kN];
+  unsigned short r_lin[kN], perm[kN];
+};
+
+template <u32 kN>
+__global__ void __launch_bounds__(kWaveTileWaves * 64) k_apply_wave(const FrameParams* __restrict__ Pp, RayArrays R, LayerView L, const int4* __restrict__ ord_info, RecordView V,
+                                                                   u32* __restrict__ tile_beg, u32* __restrict__ tile_end, Counters* cnt, u32* layer_err,
+                                                                   u32* __restrict__ h_nblocks) {
+  typedef u32 U4 __attribute__((ext_vector_type(4)));
+  typedef float F4 __attribute__((ext_vector_type(4)));
+  constexpr u32 kPer = kN / 64;  // records per lane
+  static_assert(kTileVox == 256 && kWordsPerVoxel == 3 && kN % 64 == 0, "four voxels per lane; whole rounds of records");
+  const FrameParams P = *Pp;
+  __shared__ WaveTileLds<kN> lds[kWaveTileWaves];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // last kernel of the frame (see k_apply_block)
+    if (cnt->err) atomicOr(layer_err, cnt->err);
+    *h_nblocks = min(*L.d_nblocks, L.capacity);
+  }
+  const u32 n_blocks = (cnt->err & kErrRecords) ? 0u : cnt->n_touched;
+  const u32 par = V.info->parity & 1u;
+  const u32* __restrict__ rec_key = V.key[par];
+  const u32* __restrict__ rec_ray = V.ray[par];
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  WaveTileLds<kN>& W = lds[wave];
+  const bool exact_cap = P.max_weight <= 16711680.0f;
+  u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
+  // XCD x (= workgroup index mod 8) takes the blocks with ordinal mod 8 == x; its waves take those blocks' tiles in turn
+  const u32 xcd = blockIdx.x & 7u, n_xcd_waves = (gridDim.x >> 3) * kWaveTileWaves;  // (the grid is a multiple of 8 workgroups)
+  const u32 my_tiles = ((n_blocks + 7u - xcd) >> 3) * kTilesPerBlock;                 // tiles of this XCD's blocks
+  auto tile_of = [&](u32 k) { return (((k >> kSlabBits) << 3) + xcd) * kTilesPerBlock + (k & (kTilesPerBlock - 1u)); };
+  u32 k = (blockIdx.x >> 3) * kWaveTileWaves + wave;
+  u32 nbeg = 0, nend = 0;
+  int4 ninfo = make_int4(0, 0, 0, 0);
+  if (k < my_tiles) {
+    const u32 t = tile_of(k);
+    nbeg = tile_beg[t];
+    nend = tile_end[t];
+    ninfo = ord_info[t >> kSlabBits];
+  }
+  for (; k < my_tiles; k += n_xcd_waves) {
+    const u32 tile = tile_of(k);
+    const u32 beg = nbeg, end = nend;
+    const int4 info = ninfo;
+    if (k + n_xcd_waves < my_tiles) {  // T1 of the next tile
+      const u32 t = tile_of(k + n_xcd_waves);
+      nbeg = tile_beg[t];
+      nend = tile_end[t];
+      ninfo = ord_info[t >> kSlabBits];
+    }
+    const u32 n = end - beg;
+    if (end <= beg || n > kN) continue;  // (wave-uniform) no record touches this slab of the block, or k_apply_block has taken the tile
+    if (lane == 0) {
+      tile_beg[tile] = 0;  // leave the tables empty for the next frame
+      tile_end[tile] = 0;
+    }
+    const u32 pool = static_cast<u32>(info.w);
+    if (pool == kInvalid) continue;  // (uniform; such a block's records carry invalid keys anyway)
+    const int gz = info.z + static_cast<int>(tile & (kTilesPerBlock - 1u));
+    u32* gblk = L.voxels + (static_cast<size_t>(pool) * kVoxelsPerBlock + (tile & (kTilesPerBlock - 1u)) * kTileVox) * kWordsPerVoxel;
+    // ---- T2: voxels (voxel lane + 64 q in registers) and records ----------------------------------------------------------
+    u32 vd[4], vw[4], vc[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32* g = gblk + 3u * (lane + 64u * q);
+      vd[q] = g[0];
+      vw[q] = g[1];
+      vc[q] = g[2];
+    }
+    u32 rk[kPer], rr[kPer];
+#pragma unroll
+    for (u32 t = 0; t < kPer; ++t) {
+      const u32 j = lane + 64u * t;
+      const bool on = j < n;
+      rk[t] = on ? rec_key[beg + j] : 0u;
+      rr[t] = on ? rec_ray[beg + j] : 0u;
+    }
+    reinterpret_cast<U4*>(W.acc_sum)[lane] = U4{0u, 0u, 0u, 0u};
+    reinterpret_cast<U4*>(W.acc_cnt)[lane] = U4{0u, 0u, 0u, 0u};
+    wave_lds_handover();
+    // ---- T3: the rays' lines; 1. classify, every record kept in LDS ---------------------------------------------------------
+    F4 qa[kPer];
+    float qw[kPer];
+    u32 qc[kPer];
+#pragma unroll
+    for (u32 t = 0; t < kPer; ++t) {
+      const F4* q = reinterpret_cast<const F4*>(R.q + static_cast<size_t>(rr[t]) * 8u);  // (ray 0 for the lanes beyond n: any valid line)
+      qa[t] = q[0];
+      const F4 q1 = q[1];
+      qw[t] = q1.x;
+      qc[t] = __float_as_uint(q1.y);
+    }
+#pragma unroll
+    for (u32 t = 0; t < kPer; ++t) {
+      const u32 j = lane + 64u * t;
+      if (j < n) {
+        const u32 lin = rk[t] & (kTileVox - 1u);
+        const float sdf = step_sdf(P, F3{qa[t].x, qa[t].y, qa[t].z}, qa[t].w, info.x + static_cast<int>(lin & 15u), info.y + static_cast<int>(lin >> 4), gz);
+        const float uw = update_weight(P, sdf, qw[t]);
+        bool fold = foldable_update(P, sdf, uw);
+        W.r_lin[j] = static_cast<unsigned short>(lin | (fold ? 0x8000u : 0u));
+        W.r_sdf[j] = sdf;
+        W.r_uw[j] = uw;
+        W.r_col[j] = qc[t];
+        if (fold && atomicAdd(&W.acc_sum[lin], static_cast<u32>(uw)) >= (1u << 30)) fold = false;  // the sum must stay an exact u32
+        atomicAdd(&W.acc_cnt[lin], 1u);
+        if (!fold) atomicOr(&W.acc_cnt[lin], 0x80000000u);
+      }
+    }
+    wave_lds_handover();
+    // ---- 2. fold what folds (four voxels per lane) ------------------------------------------------------------------------
+    bool any_hard = false;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32 v = lane + 64u * q;
+      const u32 c = W.acc_cnt[v], count = c & 0x7FFFFFFFu;
+      bool hard = false;
+      if (count) {
+        my_updates += count;
+        my_voxels += 1;
+        my_maxrun = max(my_maxrun, count);
+        const float d = __uint_as_float(vd[q]), w = __uint_as_float(vw[q]);
+        const u32 sum = W.acc_sum[v];
+        hard = true;
+        if (!(c >> 31) && sum < (1u << 30) && (w == 0.0f || d == P.trunc)) {
+          if (w >= P.max_weight) {
+            hard = false;  // min(max_weight, w + u) == max_weight for every u > 0: nothing changes
+          } else if (w == truncf(w) && w >= 0.0f) {
+            const unsigned long long total = static_cast<unsigned long long>(w) + sum;
+            if (total < 16777216ull || exact_cap) {
+              const float ft = static_cast<float>(total < 16777216ull ? static_cast<u32>(total) : 16777216u);
+              vd[q] = __float_as_uint(P.trunc);  // an unobserved voxel's first saturating update sets the distance to +truncation
+              vw[q] = __float_as_uint(ft >= P.max_weight ? P.max_weight : ft);
+              hard = false;
+            }
+          }
+        }
+      }
+      const u64 hm = __ballot(hard);
+      if (lane == 0) {
+        W.hardbits[2 * q] = static_cast<u32>(hm);
+        W.hardbits[2 * q + 1] = static_cast<u32>(hm >> 32);
+      }
+      any_hard |= hm != 0ull;
+    }
+    // ---- 3. the hard voxels: stable counting sort of their records by voxel, ordered replay --------------------------------
+    if (any_hard) {
+      reinterpret_cast<U4*>(W.acc_cnt)[lane] = U4{0u, 0u, 0u, 0u};
+      wave_lds_handover();
+      const u32 rounds = (n + 63u) >> 6;
+      for (u32 t = 0; t < rounds; ++t) {
+        const u32 j = lane + 64u * t;
+        if (j < n) {
+          const u32 lin = W.r_lin[j] & (kTileVox - 1u);
+          if ((W.hardbits[lin >> 5] >> (lin & 31u)) & 1u) atomicAdd(&W.acc_cnt[lin], 1u);
+        }
+      }
+      wave_lds_handover();
+      {  // exclusive scan over the 256 voxels: four consecutive voxels per lane
+        const U4 c = reinterpret_cast<const U4*>(W.acc_cnt)[lane];
+        const u32 sum = c.x + c.y + c.z + c.w;
+        const u32 ex = wave_inclusive_scan(sum) - sum;
+        reinterpret_cast<U4*>(W.acc_sum)[lane] = U4{ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z};
+      }
+      wave_lds_handover();
+      for (u32 t = 0; t < rounds; ++t) {  // ranks, 64 records at a time in record (= ray) order
+        const u32 j = lane + 64u * t;
+        u32 lin = 0;
+        bool valid = false;
+        if (j < n) {
+          lin = W.r_lin[j] & (kTileVox - 1u);
+          valid = (W.hardbits[lin >> 5] >> (lin & 31u)) & 1u;
+        }
+        u64 peers = __ballot(valid);
+        if (peers == 0ull) continue;  // (uniform)
+#pragma unroll
+        for (u32 b = 0; b < kTileShift; ++b) {
+          const bool bit = (lin >> b) & 1u;
+          const u64 m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+        const u64 lower = peers & ((1ull << lane) - 1ull);
+        if (valid) W.perm[W.acc_sum[lin] + static_cast<u32>(__popcll(lower))] = static_cast<unsigned short>(j);
+        wave_lds_handover();
+        if (valid && lower == 0ull) W.acc_sum[lin] += static_cast<u32>(__popcll(peers));
+        wave_lds_handover();
+      }
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        const u32 v = lane + 64u * q;
+        const u32 c = W.acc_cnt[v];
+        if (c) {
+          const u32 e = W.acc_sum[v];
+          Voxel vx{__uint_as_float(vd[q]), __uint_as_float(vw[q]), vc[q]};
+          for (u32 i = e - c; i < e; ++i) {
+            const u32 idx = W.perm[i];
+            const float uw = W.r_uw[idx];
+            if ((W.r_lin[idx] & 0x8000u) && vx.d == P.trunc)  // (see tile_flush)
+              vx.w = std_min(P.max_weight, vx.w + uw);
+            else
+              update_voxel(P, vx, W.r_sdf[idx], uw, W.r_col[idx]);
+          }
+          vd[q] = __float_as_uint(vx.d);
+          vw[q] = __float_as_uint(vx.w);
+          vc[q] = vx.c;
+        }
+      }
+    }
+    // ---- T4: the tile goes back --------------------------------------------------------------------------------------------
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      u32* g = gblk + 3u * (lane + 64u * q);
+      g[0] = vd[q];
+      g[1] = vw[q];
+      g[2] = vc[q];
+    }
+    wave_lds_handover();  // (the next tile reuses the wave's LDS)
+  }
+  // statistics
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    my_updates += __shfl_xor(my_updates, off, 64);
+    my_voxels += __shfl_xor(my_voxels, off, 64);
+    my_maxrun = max(my_maxrun, static_cast<u32>(__shfl_xor(static_cast<int>(my_maxrun), off, 64)));
+  }
+  if (lane == 0 && my_voxels) {
+    u32* sh = cnt->shard[(blockIdx.x * kWaveTileWaves + wave) & 63u];
     atomicAdd(&sh[kShUpdates], my_updates);
     atomicAdd(&sh[kShVoxels], my_voxels);
     atomicMax(&sh[kShMaxRun], my_maxrun);

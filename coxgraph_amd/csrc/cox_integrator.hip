@@ -75,6 +75,7 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_sorted_valid;  // valid points as seen in the sorted bundling keys (merged)
   u32 n_piece_slots;   // piece path: sum of the rays' piece bounds = slots of the piece arrays in use
   u32 n_expanded;      // piece partition: records written by k_piece_expand (what k_apply_block reads)
+  u32 n_big_tiles, n_big_chunks;  // tiles whose phase 1 is split over the chip (k_big_tiles), and their chunks
   FastCtl fast;
   // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
   // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
@@ -102,7 +103,7 @@ struct RayArrays {
   u64* key;                 // terminal voxel key (anti-grazing)
   u32* nsteps;              // records this ray emits
   u32* rec_off;             // exclusive scan of nsteps
-  float* q;                 // piece path: 8 floats per ray in one 32-B line: point_G - origin (x, y, z), its length, the ray's weight, 3 unused
+  float* q;                 // merged: 8 words per ray in one 32-B line: point_G - origin (x, y, z), its length, the ray's weight, its colour, 2 unused
   u32* pbound;              // piece path: upper bound of the ray's piece count (piece_bound)
   u32* piece_off;           // exclusive scan of pbound
 };
@@ -430,7 +431,10 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
     const bool clearing = uniform_u32(skey[begin]) >= np2;
     if (!colour_wave && lane == 0) atomicMax(&cnt->shard[m & 63u][kShMaxBundle], end - begin);
     if (colour_wave && rgba == nullptr) {  // no colours: Color() stays (0,0,0,0)
-      if (lane == 0) R.color[m] = 0u;
+      if (lane == 0) {
+        R.color[m] = 0u;
+        reinterpret_cast<u32*>(R.q)[static_cast<size_t>(m) * 8u + 5u] = 0u;
+      }
       continue;
     }
     float val = 0.0f;  // this lane's component of the running mean / colour channel
@@ -569,7 +573,10 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
       u32 mcolor = 0;
 #pragma unroll
       for (u32 c = 0; c < 4; ++c) mcolor |= (static_cast<u32>(static_cast<int>(readlane_f32(val, c))) & 255u) << (8u * c);
-      if (lane == 0) R.color[m] = mcolor;
+      if (lane == 0) {
+        R.color[m] = mcolor;
+        reinterpret_cast<u32*>(R.q)[static_cast<size_t>(m) * 8u + 5u] = mcolor;  // (the ray's line: the wave apply takes the colour from there)
+      }
     } else {
       const float mx = readlane_f32(val, 0), my = readlane_f32(val, 1), mz = readlane_f32(val, 2);
       if (lane == 0) {
@@ -591,7 +598,7 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
           typedef float F4 __attribute__((ext_vector_type(4)));
           F4* q = reinterpret_cast<F4*>(R.q + static_cast<size_t>(m) * 8u);
           q[0] = F4{dv.x, dv.y, dv.z, sqrtf(dot3(dv, dv))};
-          q[1] = F4{W, 0.0f, 0.0f, 0.0f};
+          R.q[static_cast<size_t>(m) * 8u + 4u] = W;  // (word 5 is the colour, written by the bundle's colour wave)
         }
       }
     }
@@ -1112,15 +1119,40 @@ __global__ void __launch_bounds__(256) k_depth_points(const float* __restrict__ 
 }
 
 // ---- host inputs: pinned host memory read by a kernel ------------------------------------------------------------------------
-// An experiment (COX_H2D=kernel), not the default: hipMemcpyAsync hands a pinned-to-device copy to the SDMA engine and pays two
-// engine hand-overs per copy on the frame's stream; pinned host memory is mapped into the device's address space, so an ordinary
-// kernel can read it instead (16 B per lane, grid-stride).  Measured erratic: faster for `merged`, much slower for `fast`.
+// hipMemcpyAsync hands a pinned-to-device copy to the SDMA engine and pays two engine hand-overs per copy on the frame's stream;
+// pinned host memory is mapped into the device's address space, so an ordinary kernel can read it instead.  The grid is SMALL on
+// purpose: every lane of a copy kernel sits on a PCIe read (microseconds), and a chip-filling grid of them holds the vector-memory
+// queues of every CU — kernels of neighbouring frames ran 5-8 x longer beside it (k_rs_scatter 14 -> 117 us, k_bundle_count 10 ->
+// 86 us in the kernel trace).  kCopyGroups workgroups with four 16-B loads in flight per lane (COX_H2D_GROUPS x 256 x 64 B) cover
+// the link's bandwidth-delay product (~55 GB/s x ~2 us) and leave the other CUs alone.  Two segments (points, colours) per launch.
 typedef u32 U32x4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) k_copy_from_host(U32x4* __restrict__ dst, const U32x4* __restrict__ src, size_t n16, u32* __restrict__ dst_tail,
-                                                        const u32* __restrict__ src_tail, u32 n_tail_words) {
+constexpr int kCopyGroups = 8;
+struct HostSegment {
+  U32x4* dst;
+  const U32x4* src;
+  size_t n16;
+  u32 tail_words;  // 4-byte words behind the last whole 16 bytes
+};
+__device__ __forceinline__ void copy_segment_from_host(const HostSegment& g) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(&src[i]);
-  if (blockIdx.x == 0 && threadIdx.x < n_tail_words) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  for (; i + 3 * stride < g.n16; i += 4 * stride) {
+    const U32x4 a = __builtin_nontemporal_load(&g.src[i]);
+    const U32x4 b = __builtin_nontemporal_load(&g.src[i + stride]);
+    const U32x4 c = __builtin_nontemporal_load(&g.src[i + 2 * stride]);
+    const U32x4 d = __builtin_nontemporal_load(&g.src[i + 3 * stride]);
+    g.dst[i] = a;
+    g.dst[i + stride] = b;
+    g.dst[i + 2 * stride] = c;
+    g.dst[i + 3 * stride] = d;
+  }
+  for (; i < g.n16; i += stride) g.dst[i] = __builtin_nontemporal_load(&g.src[i]);
+  if (blockIdx.x == 0 && threadIdx.x < g.tail_words)
+    reinterpret_cast<u32*>(g.dst + g.n16)[threadIdx.x] = reinterpret_cast<const u32*>(g.src + g.n16)[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_copy_from_host(const HostSegment a, const HostSegment b) {
+  copy_segment_from_host(a);
+  if (b.dst) copy_segment_from_host(b);
 }
 
 // ---- self-test: the hoisted-reciprocal division of k_bundle_merge against the compiler's IEEE '/' -----------------
@@ -1175,6 +1207,7 @@ __global__ void __launch_bounds__(256) k_selftest_division(u64 n, u64 seed, u32*
 constexpr int kStatRing = 8;
 constexpr int kFrameSets = 6;  // frames in flight: one per stage
 constexpr int kStageSets = 3;  // bundle sets (live H..M) and record sets (live T..U); kFrameSets is a multiple, so a frame slot fixes both
+constexpr int kInputSets = kFrameSets;  // staging sets for host / depth inputs: as many as frames in flight, so that filling one never has to wait on the device
 constexpr int kNumStages = 6;  // H bundle hash | P bundling sort | M bundle boundaries + means | T offsets, touch, emit | R record partition | U apply
 
 struct FrameSet {  // lives A1 .. B2
@@ -1205,6 +1238,9 @@ struct RecordSet {  // lives B1 .. B2
   u32* touched_slots = nullptr;  // [layer ht_cap]
   int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
   u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap * 16] record range of every tile (block apply); zero between frames
+  u32 *big_of_tile = nullptr, *big_acc = nullptr;  // large tiles (cox_apply_tile.hpp: BigTiles); zero between frames
+  uint2* big_chunks = nullptr;
+  u32 big_chunk_cap = 0;
   SortInfo* sort_info = nullptr;
   hipEvent_t done = nullptr;  // B2 of the frame that used this set
   bool used = false;
@@ -1310,6 +1346,7 @@ void cox_drain_submitters() {
 
 struct cox_integrator {
   Submitter* submitter = nullptr;  // COX_SUBMIT_THREAD=0 turns it off
+  uint64_t last_big_tiles = 0, last_big_chunks = 0;  // of the last frame whose counters were folded (cox_integrator_update_stats)
   uint64_t host_ns = 0, host_wait_ns = 0, host_frames = 0;  // time the caller's thread spends inside the integrate call (enqueueing, waiting for a free slot)
   cox_projective* proj = nullptr;  // method == COX_METHOD_PROJECTIVE: everything else below stays empty
   cox_layer* layer = nullptr;
@@ -1318,6 +1355,7 @@ struct cox_integrator {
   int method = 0;
   hipStream_t st[kNumStages] = {};  // stream of stage H, P, M, T, R, U (2 / 4 / 6 distinct ones, equal streams adjacent: see create)
   hipStream_t st_alt = nullptr;     // default map: ray generation (H, P, M) of the odd frame slots runs here, beside the even slots' on st[0]
+  hipStream_t st_in = nullptr;      // host inputs (copies, depth conversion) on a stream of their own: where that leaves at most four active streams
   int n_streams = 4;
   hipEvent_t ev_a2 = nullptr;  // fast: front -> record stage
   FrameSet fs[kFrameSets];
@@ -1340,6 +1378,10 @@ struct cox_integrator {
   ScanWorkspace scanws_p;       // scan of the piece lengths
   ScanWorkspace scanws_h;       // piece partition: scan over the layer's hash slots (ordinals of the stamped blocks)
   u32 piece_cap = 0;
+  u32 big_chunk = kBigChunk;
+  bool split_big_tiles = true;  // ... and the tiles of more than kBigTileMin records classified chunk by chunk (k_big_classify); COX_SPLIT_TILES=0
+  bool wave_apply = true;       // piece partition: k_apply_wave (a wave per tile) instead of k_apply_block (a workgroup per tile); COX_APPLY_WAVE=0
+  u32 grid_apply_wave = 2048, wave_tile_max = 512;  // (COX_WAVE_TILE_MAX=256|512: tiles with more records go to k_apply_block)
   bool block_apply = true;      // records partitioned by block + k_apply_block; COX_APPLY=records selects the per-record kernels (full sort)
   // ordering against the caller's stream (cox_integrator_set_input_stream): the first stage waits for what the producer has
   // enqueued, and the producer's stream waits until the engine has read the inputs (stream-ordered allocators may then
@@ -1347,21 +1389,21 @@ struct cox_integrator {
   bool has_producer = false;
   hipStream_t producer = nullptr;
   hipEvent_t ev_producer = nullptr, ev_inputs_read = nullptr;
-  float* own_xyz[kStageSets] = {};  // staging for host / depth inputs: one per bundle set (read by stages H .. M of the frame)
-  uint8_t* own_rgba[kStageSets] = {};
+  float* own_xyz[kInputSets] = {};  // staging for host / depth inputs: one per bundle set (read by stages H .. M of the frame)
+  uint8_t* own_rgba[kInputSets] = {};
   u32* depth_flag = nullptr;  // depth front end: valid pixels per tile
-  u32* d_depth_n = nullptr;   // [kStageSets] point count of the depth image converted into each staging set: it stays on the device
+  u32* d_depth_n = nullptr;   // [kInputSets] point count of the depth image converted into each staging set: it stays on the device
   // Host inputs (cox_integrate_points_async, cox_integrate_depth_async) are copied on the ray-generation stream of the frame they
   // belong to -- with the default stream map that is the OTHER ray-generation stream than the previous frame's, so the copy of
   // frame t + 1 still runs beside the kernels of frame t.  A stream of their own was tried first and fell off the cliff every fifth
   // stream falls off (merged 6 500 -> 1 640 frames/s with the extra stream).
-  float* own_depth[kStageSets] = {};       // staging for host depth images (cox_integrate_depth_async)
-  uint8_t* own_depth_rgba[kStageSets] = {};
-  hipEvent_t in_ready[kStageSets] = {};  // staging set k has been filled (the frame's first stage waits for it)
-  hipEvent_t in_free[kStageSets] = {};   // the frame that read staging set k last has read it for the last time
-  bool in_used[kStageSets] = {};
-  float* pin_xyz[kStageSets] = {};       // pinned bounce buffers for pageable host inputs (a pinned caller buffer is copied from directly)
-  uint8_t* pin_rgba[kStageSets] = {};
+  float* own_depth[kInputSets] = {};       // staging for host depth images (cox_integrate_depth_async)
+  uint8_t* own_depth_rgba[kInputSets] = {};
+  hipEvent_t in_ready[kInputSets] = {};  // staging set k has been filled (the frame's first stage waits for it)
+  hipEvent_t in_free[kInputSets] = {};   // the frame that read staging set k last has read it for the last time
+  bool in_used[kInputSets] = {};
+  float* pin_xyz[kInputSets] = {};       // pinned bounce buffers for pageable host inputs (a pinned caller buffer is copied from directly)
+  uint8_t* pin_rgba[kInputSets] = {};
   u32 pin_cap = 0;
   SortWorkspace sort_pts, sort_rec, sort_vis, sort_vis1;  // sort_vis / sort_vis1: the fast integrator's visit sorts (round 0 on the start-set stream, round 1 on the solve's)
   ScanWorkspace scanws_a, scanws_b, scanws_d, scanws_f;
@@ -1434,6 +1476,7 @@ static int sync_all(cox_integrator* I) {
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) COX_HIP(hipStreamSynchronize(I->st[k]));
   if (I->st_alt) COX_HIP(hipStreamSynchronize(I->st_alt));
+  if (I->st_in) COX_HIP(hipStreamSynchronize(I->st_in));
   return COX_OK;
 }
 
@@ -1478,7 +1521,7 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
     COX_TRY(dev_realloc(&B.head, cap));
     COX_TRY(dev_realloc(&B.bstart, cap));
   }
-  for (int k = 0; k < kStageSets; ++k) {
+  for (int k = 0; k < kInputSets; ++k) {
     COX_TRY(dev_realloc(&I->own_xyz[k], static_cast<size_t>(cap) * 3));
     COX_TRY(dev_realloc(&I->own_rgba[k], static_cast<size_t>(cap) * 4));
     COX_TRY(dev_realloc(&I->own_depth[k], cap));
@@ -1514,6 +1557,8 @@ static int ensure_capacity(cox_integrator* I, u32 n) {
         COX_TRY(dev_realloc(&S.pdest, piece_cap));
         COX_TRY(dev_realloc(&S.rec_key[0], rcap));
         COX_TRY(dev_realloc(&S.rec_ray[0], rcap));
+        S.big_chunk_cap = static_cast<u32>(rcap / kBigChunkMin) + kBigCap + 1u;
+        COX_TRY(dev_realloc(&S.big_chunks, S.big_chunk_cap));
       }
       continue;
     }
@@ -1908,14 +1953,32 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
   if (I->block_apply) {
     if (!I->piece_sort)  // (piece partition: the ranges come with the expansion, k_piece_tile_ranges)
       hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift, I->bucket_partition ? 4095u : 0xFFFFFFFFu);
+    u32 min_records = 0;
+    BigTiles big{nullptr, nullptr, nullptr, 0, 0};
 #define COX_LAUNCH_APPLY(Q, TS, BUCKET)                                                                                                                       \
   hipLaunchKernelGGL((k_apply_block<Q, TS, BUCKET>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, \
-                     I->layer->d_err, I->layer->h_nblocks)
+                     I->layer->d_err, I->layer->h_nblocks, min_records, big)
     if (I->method == COX_METHOD_MERGED) {  // the merge leaves RayArrays::q
       if (I->piece_sort) {                 // tile ranges straight from the pieces (k_piece_tile_ranges)
         if (I->tile_shift == 9)
           COX_LAUNCH_APPLY(true, 9, false);
-        else
+        else if (I->wave_apply) {  // fine voxels (cox_apply_tile.hpp): the largest tiles classified chunk by chunk by the whole chip, a
+                                   // workgroup per tile for the large ones, a wave per tile for the rest
+          min_records = I->wave_tile_max + 1;
+          if (const char* e = std::getenv("COX_DEBUG_BLOCK_MIN")) min_records = static_cast<u32>(std::atoi(e));  // (timing experiments: drops tiles)
+          if (I->split_big_tiles && S.big_chunks) {
+            big = BigTiles{S.big_of_tile, S.big_acc, S.big_chunks, S.big_chunk_cap, I->big_chunk};
+            hipLaunchKernelGGL(k_big_tiles, dim3(512), dim3(256), 0, s, S.blk_beg, S.blk_end, S.ord_info, F.cnt, big);
+            hipLaunchKernelGGL((k_big_classify<true>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, S.ord_info, V, S.blk_end, F.cnt, big);
+          }
+          COX_LAUNCH_APPLY(true, 8, false);
+          if (I->wave_tile_max == 256)
+            hipLaunchKernelGGL((k_apply_wave<256>), dim3(std::max(8u, I->grid_apply_wave & ~7u)), dim3(kWaveTileWaves * 64), 0, s, F.d_params, F.rays, L, S.ord_info, V,
+                               S.blk_beg, S.blk_end, F.cnt, I->layer->d_err, I->layer->h_nblocks);
+          else
+            hipLaunchKernelGGL((k_apply_wave<512>), dim3(std::max(8u, I->grid_apply_wave & ~7u)), dim3(kWaveTileWaves * 64), 0, s, F.d_params, F.rays, L, S.ord_info, V,
+                               S.blk_beg, S.blk_end, F.cnt, I->layer->d_err, I->layer->h_nblocks);
+        } else
           COX_LAUNCH_APPLY(true, 8, false);
       } else if (!I->bucket_partition) {
         if (I->tile_shift == 9)
@@ -2134,6 +2197,10 @@ static int follow_layer(cox_integrator* I) {
       COX_TRY(dev_realloc(&S.blk_end, static_cast<size_t>(Lh->ht_cap) * kTilesPerBlock));
       COX_HIP(hipMemset(S.blk_beg, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
       COX_HIP(hipMemset(S.blk_end, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
+      if (I->piece_sort) {
+        COX_TRY(dev_realloc(&S.big_of_tile, static_cast<size_t>(Lh->ht_cap) * kTilesPerBlock));
+        COX_HIP(hipMemset(S.big_of_tile, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
+      }
       COX_HIP(hipDeviceSynchronize());
     }
     if (I->piece_sort) COX_TRY(dev_realloc(&I->scanws_h.block_sums, scan_num_blocks(Lh->ht_cap) + 2));
@@ -2325,6 +2392,8 @@ static int fold_counters(cox_integrator* I) {
   I->last.n_touched_voxels = sh[kShVoxels];
   I->last.n_touched_blocks = c.n_touched;
   I->last.n_new_blocks = c.n_new_blocks;
+  I->last_big_tiles = c.n_big_tiles;
+  I->last_big_chunks = c.n_big_chunks;
   I->last_has_counts = false;  // folded; I->last keeps the numbers
   return COX_OK;
 }
@@ -2412,6 +2481,11 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   // Bit-identical and covered by the parity tests, but not the default: the piece sort is 2.3x cheaper than the record sort at
   // 1 cm, the piece apply 1.75x dearer than the record apply -- even at 1 cm, slower at 2 cm and 5 cm
   if (const char* e = std::getenv("COX_GRID_APPLY")) I->grid_apply = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("COX_GRID_APPLY_WAVE")) I->grid_apply_wave = static_cast<u32>(std::max(8, std::atoi(e)));
+  if (const char* e = std::getenv("COX_APPLY_WAVE")) I->wave_apply = std::atoi(e) != 0;
+  if (const char* e = std::getenv("COX_SPLIT_TILES")) I->split_big_tiles = std::atoi(e) != 0;
+  if (const char* e = std::getenv("COX_BIG_CHUNK")) I->big_chunk = static_cast<u32>(std::max<int>(kBigChunkMin, std::atoi(e)));
+  if (const char* e = std::getenv("COX_WAVE_TILE_MAX")) I->wave_tile_max = std::atoi(e) == 256 ? 256u : 512u;
   if (const char* e = std::getenv("COX_GRID_MERGE")) I->grid_merge = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("COX_GRID_TOUCH")) I->grid_touch = std::max(1, std::atoi(e));
   I->piece_path = method == COX_METHOD_MERGED && !cfg->enable_anti_grazing && std::getenv("COX_APPLY") && std::string(std::getenv("COX_APPLY")) == "pieces";
@@ -2450,17 +2524,26 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     // Default (four streams): H P M | H P M | T R | U -- ray generation depends on the frame's input only, so two frames run
     // it side by side (even / odd frame slots), and the frame rate no longer hangs on the longest ray-generation chain (the
     // merge of a frame with large bundles: 105 us); the layer update stays one pipeline, in frame order.
-    // In between -- the piece partition at moderate ray lengths (2 cm: 5 * 10^6 records per frame, the layer update three times
-    // the ray generation, its kernels still latency-bound) -- the four streams go to H P M | T | R | U instead: 2 456 -> 2 910
-    // frames/s at 2 cm; at 1 cm (2.5 * 10^7 records, throughput-bound kernels) that map loses 7 %, so it keeps the default.
+    // Where the layer update is several times the ray generation -- the piece partition: 2 cm and finer -- the four streams go to
+    // H P M | T | R | U instead: 2 456 -> 2 910 frames/s at 2 cm; at 1 cm that map lost 7 % while the apply was 0.8 ms of one
+    // workgroup's time (round 2) and gains 9 % since the large tiles are split (752 -> 823, round 3).
     // fast: front | solve | update (fast_front / fast_solve): st[0] | st[1] == st[2] | st[3] == st[4] == st[5]; COX_FAST_STREAMS=1 puts
     // all three on one stream (round 2's arrangement).
     static const int kMap[6][kNumStages] = {{0, 0, 0, 1, 1, 1}, {0, 0, 1, 2, 2, 3}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 1, 1, 2}, {0, 0, 0, 1, 2, 3}, {0, 1, 1, 2, 2, 2}};
     const bool chosen = std::getenv("COX_STREAM_MAP") || std::getenv("COX_STREAMS");
-    const bool update_heavy = !chosen && method == COX_METHOD_MERGED && I->piece_sort && (max_steps_per_ray(I) - 1) / 3 <= 200;
-    const bool parity = I->n_streams == 4 && method != COX_METHOD_FAST && !std::getenv("COX_STREAM_MAP") && !update_heavy &&
+    const bool update_heavy = !chosen && method == COX_METHOD_MERGED && I->piece_sort;
+    const bool parity = (I->n_streams == 4 || (std::getenv("COX_STREAMS") && std::string(std::getenv("COX_STREAMS")) == "3p")) && method != COX_METHOD_FAST && !std::getenv("COX_STREAM_MAP") && !update_heavy &&
                         !(std::getenv("COX_STREAMS") && std::string(std::getenv("COX_STREAMS")) == "4s");  // COX_STREAMS=4s: the staged map H P | M | T R | U
-    const int* map = kMap[method == COX_METHOD_FAST ? 5 : update_heavy ? 4 : parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    const bool three_p = std::getenv("COX_STREAMS") && std::string(std::getenv("COX_STREAMS")) == "3p";  // H P M | H P M | T R U
+    const int* map = kMap[method == COX_METHOD_FAST ? 5 : update_heavy ? 4 : three_p ? 0 : parity ? 3 : I->n_streams == 2 ? 0 : I->n_streams == 4 ? 1 : 2];
+    // The input stream (host buffers -> staging sets) is created FIRST, directly in front of the stage streams: the hardware queues of
+    // a process are spread over the four pipes of the compute micro-engine in creation order, so four stage streams created back to
+    // back sit on four different pipes, and the input stream lands on the pipe of the LAST of them -- the apply's (two long kernels
+    // per frame), the partner that minds least (sharing with T/R costs 35 %, with a ray-generation stream 45 %).
+    // `fast` has three stage streams: its input stream has a pipe to itself.  COX_INPUT_STREAM=0: inputs ride on the frame's own stream.
+    if (!(std::getenv("COX_INPUT_STREAM") && std::atoi(std::getenv("COX_INPUT_STREAM")) == 0) && st == COX_OK &&
+        hipStreamCreateWithFlags(&I->st_in, hipStreamNonBlocking) != hipSuccess)
+      st = COX_ERR_NO_DEVICE;
     if (parity && st == COX_OK && hipStreamCreateWithFlags(&I->st_alt, hipStreamNonBlocking) != hipSuccess) st = COX_ERR_NO_DEVICE;
     int custom[kNumStages];
     if (const char* e = std::getenv("COX_STREAM_MAP")) {  // experiments: six digits, stage -> stream, equal streams adjacent (e.g. 012334)
@@ -2503,7 +2586,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     }
   }
   ev(&I->ev_a2);
-  for (int k = 0; k < kStageSets; ++k) {
+  for (int k = 0; k < kInputSets; ++k) {
     if (st == COX_OK && hipEventCreateWithFlags(&I->in_ready[k], hipEventDisableTiming) != hipSuccess) st = COX_ERR_NO_DEVICE;
     ev(&I->in_free[k]);
   }
@@ -2534,6 +2617,13 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     if (st == COX_OK && (hipMemset(S.blk_beg, 0, sizeof(u32) * layer->ht_cap * kTilesPerBlock) != hipSuccess ||
                          hipMemset(S.blk_end, 0, sizeof(u32) * layer->ht_cap * kTilesPerBlock) != hipSuccess))
       st = COX_ERR_NO_DEVICE;
+    if (st == COX_OK && I->piece_sort) {
+      st = dev_realloc(&S.big_of_tile, static_cast<size_t>(layer->ht_cap) * kTilesPerBlock);
+      if (st == COX_OK) st = dev_realloc(&S.big_acc, static_cast<size_t>(kBigCap) * 2 * kTileVox);
+      if (st == COX_OK && (hipMemset(S.big_of_tile, 0, sizeof(u32) * layer->ht_cap * kTilesPerBlock) != hipSuccess ||
+                           hipMemset(S.big_acc, 0, sizeof(u32) * kBigCap * 2 * kTileVox) != hipSuccess))
+        st = COX_ERR_NO_DEVICE;
+    }
     info(&S.sort_info);
   }
   if (st == COX_OK && I->piece_sort) st = dev_realloc(&I->scanws_h.block_sums, scan_num_blocks(layer->ht_cap) + 2);
@@ -2541,7 +2631,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
     st = COX_ERR_OUT_OF_MEMORY;
   if (st == COX_OK && hipHostMalloc(reinterpret_cast<void**>(&I->h_params), sizeof(FrameParams) * kFrameSets, hipHostMallocDefault) != hipSuccess)
     st = COX_ERR_OUT_OF_MEMORY;
-  if (st == COX_OK) st = dev_realloc(&I->d_depth_n, kStageSets);
+  if (st == COX_OK) st = dev_realloc(&I->d_depth_n, kInputSets);
   if (st == COX_OK && method == COX_METHOD_FAST) {
     FastState& X = I->fast;
     st = dev_realloc(&X.table_start, kFastSlots);
@@ -2618,7 +2708,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
   if (I->timeline_ref) (void)hipEventDestroy(I->timeline_ref);
   if (I->timeline) fclose(I->timeline);
-  std::vector<void*> ptrs = {I->own_xyz[0], I->own_xyz[1], I->own_xyz[2], I->own_rgba[0], I->own_rgba[1], I->own_rgba[2], I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_pts_alt.counts, I->sort_pts_alt.totals, I->sort_rec.counts,
+  std::vector<void*> ptrs = {I->depth_flag, I->d_depth_n, I->sort_pts.counts, I->sort_pts.totals, I->sort_pts_alt.counts, I->sort_pts_alt.totals, I->sort_rec.counts,
                              I->sort_rec.totals, I->sort_vis.counts, I->sort_vis.totals, I->sort_vis1.counts, I->sort_vis1.totals, I->scanws_a.block_sums, I->scanws_b.block_sums, I->scanws_d.block_sums,
                              I->scanws_f.block_sums, I->scanws_p.block_sums, I->scanws_h.block_sums};
   std::vector<hipEvent_t> events = {I->ev_a2, I->ev_producer, I->ev_inputs_read};
@@ -2658,7 +2748,8 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (RecordSet& S : I->rs) {
     for (void* p : {static_cast<void*>(S.rec_key[0]), static_cast<void*>(S.rec_key[1]), static_cast<void*>(S.rec_ray[0]), static_cast<void*>(S.rec_ray[1]),
                     static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots), static_cast<void*>(S.ord_info),
-                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end), static_cast<void*>(S.lin8), static_cast<void*>(S.pkey[0]),
+                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end), static_cast<void*>(S.big_of_tile), static_cast<void*>(S.big_acc),
+                    static_cast<void*>(S.big_chunks), static_cast<void*>(S.lin8), static_cast<void*>(S.pkey[0]),
                     static_cast<void*>(S.pkey[1]), static_cast<void*>(S.pstart[0]), static_cast<void*>(S.pstart[1]), static_cast<void*>(S.prl[0]),
                     static_cast<void*>(S.prl[1]), static_cast<void*>(S.pbkey), static_cast<void*>(S.plen), static_cast<void*>(S.pdest),
                     static_cast<void*>(S.sort_info)})
@@ -2670,13 +2761,15 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   if (I->h_ring) (void)hipHostFree(I->h_ring);
-  for (int k = 0; k < kStageSets; ++k) {
+  for (int k = 0; k < kInputSets; ++k) {
     if (I->pin_xyz[k]) (void)hipHostFree(I->pin_xyz[k]);
     if (I->pin_rgba[k]) (void)hipHostFree(I->pin_rgba[k]);
     if (I->in_ready[k]) (void)hipEventDestroy(I->in_ready[k]);
     if (I->in_free[k]) (void)hipEventDestroy(I->in_free[k]);
   }
-  for (int k = 0; k < kStageSets; ++k) {
+  for (int k = 0; k < kInputSets; ++k) {
+    if (I->own_xyz[k]) (void)hipFree(I->own_xyz[k]);
+    if (I->own_rgba[k]) (void)hipFree(I->own_rgba[k]);
     if (I->own_depth[k]) (void)hipFree(I->own_depth[k]);
     if (I->own_depth_rgba[k]) (void)hipFree(I->own_depth_rgba[k]);
   }
@@ -2684,6 +2777,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (int k = 0; k < kNumStages; ++k)
     if (I->st[k] && (k == 0 || I->st[k] != I->st[k - 1])) (void)hipStreamDestroy(I->st[k]);
   if (I->st_alt) (void)hipStreamDestroy(I->st_alt);
+  if (I->st_in) (void)hipStreamDestroy(I->st_in);
   delete I;
   (void)hipGetLastError();
 }
@@ -2720,28 +2814,48 @@ static const void* host_pointer_device_view(const void* p) {
   if (a.type != hipMemoryTypeHost) return nullptr;
   return a.devicePointer ? a.devicePointer : p;
 }
-// bytes (a multiple of 4) from pinned host memory, seen by the device at src_dev, to dst on stream s
-static int copy_pinned_to_device(void* dst, const void* src_host, const void* src_dev, size_t bytes, hipStream_t s) {
-  // (COX_H2D=kernel selects it; not the default: merged 3.0 k -> 3.8 k frames/s from pinned clouds in one run, fast 2.1 k -> 0.8 k in the same run)
-  static const bool use_kernel = std::getenv("COX_H2D") && std::string(std::getenv("COX_H2D")) == "kernel";
-  if (!use_kernel || (reinterpret_cast<uintptr_t>(src_dev) & 15u) || (reinterpret_cast<uintptr_t>(dst) & 15u) || (bytes & 3u)) {
-    COX_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, s));
+// one or two arrays (bytes a multiple of 4) from pinned host memory, seen by the device at src_dev_*, to dst_* on stream s
+static int copy_pinned_to_device(void* dst_a, const void* src_a, const void* src_dev_a, size_t bytes_a, void* dst_b, const void* src_b, const void* src_dev_b,
+                                 size_t bytes_b, hipStream_t s) {
+  static const bool use_memcpy = !(std::getenv("COX_H2D") && std::string(std::getenv("COX_H2D")) == "kernel");
+  static const int groups = std::getenv("COX_H2D_GROUPS") ? std::max(1, std::atoi(std::getenv("COX_H2D_GROUPS"))) : kCopyGroups;
+  auto unaligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
+  const bool two = dst_b != nullptr;
+  if (use_memcpy || !src_dev_a || unaligned(src_dev_a) || unaligned(dst_a) || (bytes_a & 3u) ||
+      (two && (!src_dev_b || unaligned(src_dev_b) || unaligned(dst_b) || (bytes_b & 3u)))) {
+    COX_HIP(hipMemcpyAsync(dst_a, src_a, bytes_a, hipMemcpyHostToDevice, s));
+    if (two) COX_HIP(hipMemcpyAsync(dst_b, src_b, bytes_b, hipMemcpyHostToDevice, s));
     return COX_OK;
   }
-  const size_t n16 = bytes / 16;
-  const u32 tail_words = static_cast<u32>((bytes - 16 * n16) / 4);
-  hipLaunchKernelGGL(k_copy_from_host, dim3(1024), dim3(256), 0, s, static_cast<U32x4*>(dst), static_cast<const U32x4*>(src_dev), n16,
-                     reinterpret_cast<u32*>(static_cast<char*>(dst) + 16 * n16), reinterpret_cast<const u32*>(static_cast<const char*>(src_dev) + 16 * n16), tail_words);
+  HostSegment A{static_cast<U32x4*>(dst_a), static_cast<const U32x4*>(src_dev_a), bytes_a / 16, static_cast<u32>((bytes_a & 15u) / 4)};
+  HostSegment B{nullptr, nullptr, 0, 0};
+  if (two) B = HostSegment{static_cast<U32x4*>(dst_b), static_cast<const U32x4*>(src_dev_b), bytes_b / 16, static_cast<u32>((bytes_b & 15u) / 4)};
+  hipLaunchKernelGGL(k_copy_from_host, dim3(groups), dim3(256), 0, s, A, B);
   return COX_OK;
 }
 // the stream the next frame's first stage will run on
-static inline hipStream_t next_input_stream(const cox_integrator* I) { return stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets)); }
+static inline hipStream_t next_frame_stream(const cox_integrator* I) { return stage_stream(I, 0, static_cast<int>((I->frame_no + 1) % kFrameSets)); }
+// ... and the stream host inputs are staged on: the input stream, or (COX_INPUT_STREAM=0) the frame's own
+static inline hipStream_t next_input_stream(const cox_integrator* I) { return I->st_in ? I->st_in : next_frame_stream(I); }
+// Staging set k was read last by the frame kInputSets frames ago (its stages H .. M, enqueued by the caller's thread: the event is
+// recorded by now).  On the frame's own stream that is a device-side wait; on the input stream it is a HOST wait -- the caller can
+// not be more than kFrameSets frames ahead of the device anyway (frame slots), and the input stream's queue then carries nothing
+// but the copies and one event record per frame: no barrier packet that holds its pipe.
+static int wait_staging_set_free(cox_integrator* I, int k, hipStream_t s_in) {
+  if (!I->in_used[k]) return COX_OK;
+  if (s_in == I->st_in) {
+    COX_HIP(hipEventSynchronize(I->in_free[k]));
+  } else {
+    COX_HIP(hipStreamWaitEvent(s_in, I->in_free[k], 0));
+  }
+  return COX_OK;
+}
 // two host arrays (a: a_bytes per element, b: b_bytes per element or absent) -> the device buffers dst_a / dst_b
 static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_bytes, void* dst_a, const void* b, size_t b_bytes, void* dst_b, u32 n, FrameInput* in) {
   const hipStream_t s_in = next_input_stream(I);
   // the staging set is free once the frame that used it three frames ago has read it for the last time; that frame's stages
   // H .. M are enqueued by the caller's thread, so the event is recorded by now
-  if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s_in, I->in_free[k], 0));
+  COX_TRY(wait_staging_set_free(I, k, s_in));
   const void* dev_a = host_pointer_device_view(a);
   const void* dev_b = b ? host_pointer_device_view(b) : nullptr;
   const bool pinned = dev_a != nullptr && (!b || dev_b != nullptr);
@@ -2750,7 +2864,7 @@ static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_b
   if (!pinned) {
     if (I->pin_cap < I->pcap) {
       COX_TRY(sync_all(I));
-      for (int q = 0; q < kStageSets; ++q) {
+      for (int q = 0; q < kInputSets; ++q) {
         if (I->pin_xyz[q]) (void)hipHostFree(I->pin_xyz[q]);
         if (I->pin_rgba[q]) (void)hipHostFree(I->pin_rgba[q]);
         I->pin_xyz[q] = nullptr;
@@ -2773,16 +2887,10 @@ static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_b
     dev_a = host_pointer_device_view(src_a);
     dev_b = b ? host_pointer_device_view(src_b) : nullptr;
   }
-  if (dev_a && (!b || dev_b)) {
-    COX_TRY(copy_pinned_to_device(dst_a, src_a, dev_a, a_bytes * n, s_in));
-    if (b) COX_TRY(copy_pinned_to_device(dst_b, src_b, dev_b, b_bytes * n, s_in));
-  } else {
-    COX_HIP(hipMemcpyAsync(dst_a, src_a, a_bytes * n, hipMemcpyHostToDevice, s_in));
-    if (b) COX_HIP(hipMemcpyAsync(dst_b, src_b, b_bytes * n, hipMemcpyHostToDevice, s_in));
-  }
+  COX_TRY(copy_pinned_to_device(dst_a, src_a, dev_a, a_bytes * n, b ? dst_b : nullptr, src_b, dev_b, b ? b_bytes * n : 0, s_in));
   COX_HIP(hipEventRecord(I->in_ready[k], s_in));
   I->in_used[k] = true;
-  in->ready = nullptr;  // (same stream as the frame's first stage: stream order)
+  in->ready = I->st_in ? I->in_ready[k] : nullptr;  // (without an input stream: same stream as the frame's first stage, stream order)
   in->consumed = I->in_free[k];
   return COX_OK;
 }
@@ -2794,15 +2902,16 @@ int cox_integrate_points(cox_integrator_t* I, const float T_G_C[7], const float*
   if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
   if (I->submitter) I->submitter->wait_outstanding(0);
-  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);  // the bundle set of the frame about to be enqueued
+  const int k = static_cast<int>((I->frame_no + 1) % kInputSets);  // the bundle set of the frame about to be enqueued
   FrameInput in;
   if (n) {  // synchronous call: copied straight from the caller's buffers (the runtime stages pageable memory itself), the call returns after the frame
     const hipStream_t s_in = next_input_stream(I);
-    if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s_in, I->in_free[k], 0));
+    COX_TRY(wait_staging_set_free(I, k, s_in));
     COX_HIP(hipMemcpyAsync(I->own_xyz[k], xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, s_in));
     if (rgba) COX_HIP(hipMemcpyAsync(I->own_rgba[k], rgba, 4 * n, hipMemcpyHostToDevice, s_in));
     COX_HIP(hipEventRecord(I->in_ready[k], s_in));
     I->in_used[k] = true;
+    in.ready = I->st_in ? I->in_ready[k] : nullptr;
     in.consumed = I->in_free[k];
   }
   COX_TRY(integrate_device(I, T_G_C, I->own_xyz[k], rgba ? I->own_rgba[k] : nullptr, static_cast<u32>(n), freespace, true, in));
@@ -2816,7 +2925,7 @@ int cox_integrate_points_async(cox_integrator_t* I, const float T_G_C[7], const 
   if (I->proj) return cox_proj_integrate_host(I->proj, T_G_C, xyz, n, 0);
   COX_TRY(ensure_capacity(I, static_cast<u32>(n)));
   if (I->submitter) I->submitter->wait_outstanding(1);
-  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
+  const int k = static_cast<int>((I->frame_no + 1) % kInputSets);
   FrameInput in;
   if (n) COX_TRY(stage_host_inputs(I, k, xyz, sizeof(float) * 3, I->own_xyz[k], rgba, 4, I->own_rgba[k], static_cast<u32>(n), &in));
   // (the staging buffers are the engine's own: no ordering against the caller's stream for them)
@@ -2832,7 +2941,7 @@ int cox_integrator_wait_inputs(cox_integrator_t* I) {
   if (!I) return COX_ERR_INVALID_ARG;
   if (I->proj) return COX_OK;  // (the projective integrator's host entry point is synchronous)
   COX_HIP(hipSetDevice(I->layer->device));
-  for (int k = 0; k < kStageSets; ++k)
+  for (int k = 0; k < kInputSets; ++k)
     if (I->in_used[k]) COX_HIP(hipEventSynchronize(I->in_ready[k]));
   return COX_OK;
 }
@@ -2858,9 +2967,9 @@ int cox_integrate_depth_dev(cox_integrator_t* I, const float T_G_C[7], const flo
   // (read by its stages H .. M), converted on the frame's ray-generation stream, and the point count -- which the "mixed" visiting
   // order is a function of -- stays in device memory: the frame's first kernel takes it from there (k_bundle_insert / k_params_count).
   if (I->submitter) I->submitter->wait_outstanding(1);
-  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
-  const hipStream_t s = next_input_stream(I);
-  if (I->in_used[k]) COX_HIP(hipStreamWaitEvent(s, I->in_free[k], 0));
+  const int k = static_cast<int>((I->frame_no + 1) % kInputSets);
+  const hipStream_t s = next_frame_stream(I);  // (not the input stream: a wait for the caller's stream would sit in its queue)
+  COX_TRY(wait_staging_set_free(I, k, s));
   if (I->has_producer) {  // the images were written on the caller's stream
     COX_HIP(hipEventRecord(I->ev_producer, I->producer));
     COX_HIP(hipStreamWaitEvent(s, I->ev_producer, 0));
@@ -2891,10 +3000,21 @@ int cox_integrate_depth_async(cox_integrator_t* I, const float T_G_C[7], const f
   const u32 n = static_cast<u32>(w) * static_cast<u32>(h);
   COX_TRY(ensure_capacity(I, n));
   if (I->submitter) I->submitter->wait_outstanding(1);
-  const int k = static_cast<int>((I->frame_no + 1) % kStageSets);
+  const int k = static_cast<int>((I->frame_no + 1) % kInputSets);
   FrameInput in;
   COX_TRY(stage_host_inputs(I, k, depth, sizeof(float), I->own_depth[k], rgba, 4, I->own_depth_rgba[k], n, &in));
-  convert_depth(I, k, I->own_depth[k], rgba ? I->own_depth_rgba[k] : nullptr, w, h, K, next_input_stream(I));
+  // the conversion (two kernels) runs on the frame's own stream behind the copies' event: the input stream shares the apply's pipe for
+  // `merged`, and kernels there cost more than 25 us on the ray-generation chain do (640x480 images, frames/s: 6 380 vs 5 170; `fast`,
+  // whose input stream has a pipe of its own: 2 780 vs 2 830).  COX_DEPTH_CONVERT=input puts it on the input stream.
+  static const bool on_frame_stream = !(std::getenv("COX_DEPTH_CONVERT") && std::string(std::getenv("COX_DEPTH_CONVERT")) == "input");
+  if (I->st_in && on_frame_stream) {
+    COX_HIP(hipStreamWaitEvent(next_frame_stream(I), I->in_ready[k], 0));
+    in.ready = nullptr;
+    convert_depth(I, k, I->own_depth[k], rgba ? I->own_depth_rgba[k] : nullptr, w, h, K, next_frame_stream(I));
+  } else {
+    convert_depth(I, k, I->own_depth[k], rgba ? I->own_depth_rgba[k] : nullptr, w, h, K, next_input_stream(I));
+    if (I->st_in) COX_HIP(hipEventRecord(I->in_ready[k], I->st_in));  // (recorded again: behind the conversion)
+  }
   in.n_dev = I->d_depth_n + k;
   const bool producer = I->has_producer;
   I->has_producer = false;
@@ -3027,6 +3147,18 @@ int cox_integrator_fast_stats(cox_integrator_t* I, uint64_t out[10]) {
   out[9] = static_cast<uint64_t>(h[8]) * 10ull;
   if (std::getenv("COX_DEBUG")) fprintf(stderr, "[coxgraph_hip] fast: long rays %u, visits of the last round %llu, of round 0 %llu (totals over %llu frames)\n", h[9],
                                         static_cast<unsigned long long>(h[10]) * 16ull, static_cast<unsigned long long>(h[11]) * 16ull, static_cast<unsigned long long>(I->fast.frames));
+  return COX_OK;
+}
+
+int cox_integrator_update_stats(cox_integrator_t* I, uint64_t out[2]) {
+  COX_ENTRY();
+  if (!I || !out) return COX_ERR_INVALID_ARG;
+  out[0] = out[1] = 0;
+  if (I->proj) return COX_OK;
+  COX_HIP(hipSetDevice(I->layer->device));
+  COX_TRY(integrator_finish(I));
+  out[0] = I->last_big_tiles;
+  out[1] = I->last_big_chunks;
   return COX_OK;
 }
 

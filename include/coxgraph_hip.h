@@ -247,6 +247,10 @@ int cox_integrator_class_times(cox_integrator_t* integ, double ms[COX_KERNEL_CLA
  * relaxation spent in the passes' own work / waiting at their barriers (where the slowest workgroup's work shows).  No reference
  * counterpart (measurement only).  Waits for the frames in flight. */
 int cox_integrator_fast_stats(cox_integrator_t* integ, uint64_t out[10]);
+/* layer update of the last frame (measurement only, no reference counterpart): out[0] tiles whose classification was split over the
+ * chip (more records than two chunks; piece partition = fine voxels only, else 0), out[1] the chunks they were cut into.  Waits for
+ * the frames in flight. */
+int cox_integrator_update_stats(cox_integrator_t* integ, uint64_t out[2]);
 
 /* self-test: the merged integrator evaluates its sequential mean with an IEEE division whose divisor-only part is
  * hoisted out of the dependent chain; this compares it bit for bit with the compiler's '/' on n pseudo-random operand

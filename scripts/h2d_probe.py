@@ -43,6 +43,16 @@ if not os.environ.get("PROBE_SKIP_RAW"):
             print(f"raw copy {mb} MB, {n_streams} stream(s): submit {(t1 - t0) / 200 * 1e6:.1f} us/copy, done {(t2 - t0) / 200 * 1e6:.1f} us/copy = {nb / ((t2 - t0) / 200) / 1e9:.1f} GB/s", flush=True)
         del src, dst
 
+# streams created (and never used) before the engine's own: does the NUMBER of streams of the process matter, or only the active ones?
+if os.environ.get("PROBE_DUMMY_STREAMS"):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    dummies = []
+    for _ in range(int(os.environ["PROBE_DUMMY_STREAMS"])):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0
+        dummies.append(h)
+
 # ---- B: the engine ------------------------------------------------------------------------------------------------------
 host = [synth.make_frame(t) for t in range(n)]
 dev = [(T, torch.from_numpy(p).cuda(), torch.from_numpy(c).cuda(), p.shape[0]) for T, p, c, _ in host]
@@ -50,7 +60,7 @@ pinned = [(T, torch.from_numpy(p).pin_memory(), torch.from_numpy(c).pin_memory()
 torch.cuda.synchronize()
 
 
-def run(label, call, frames, reps=3):
+def run(label, call, frames, reps=int(os.environ.get('PROBE_REPS', '3'))):
     for rep in range(reps):
         integ = Integrator(eng, Layer(eng, voxel, capacity_blocks=32768), cfg, method)
         for f in frames[:10]:
@@ -72,5 +82,62 @@ def run(label, call, frames, reps=3):
 
 
 run("resident", lambda I, f: I.integrate_points_dev(f[0], f[1].data_ptr(), f[2].data_ptr(), f[3]), dev)
+if os.environ.get("PROBE_RESIDENT_ONLY"):
+    sys.exit(0)
 run("pinned xyz+rgba", lambda I, f: I.integrate_points_async(f[0], f[1].data_ptr(), f[2].data_ptr(), f[1].shape[0]), pinned)
+K = np.array(synth.INTRINSICS[(640, 480)], np.float32)
+rgba_img = torch.from_numpy(synth.frame_colors(640, 480)).pin_memory()
+pinned_d = [(T, torch.from_numpy(d).pin_memory()) for T, _, _, d in host]
+run("pinned depth+rgba images", lambda I, f: I.integrate_depth_async(f[0], f[1].data_ptr(), rgba_img.data_ptr(), 640, 480, K), pinned_d)
+import ctypes
+_hip = ctypes.CDLL("libamdhip64.so")
+_h = ctypes.c_void_p()
+assert _hip.hipStreamCreateWithFlags(ctypes.byref(_h), 1) == 0
+side = torch.cuda.ExternalStream(_h.value)
+dd = [torch.empty(640 * 480, dtype=torch.float32, device="cuda") for _ in range(8)]
+cc = [torch.empty(640 * 480 * 4, dtype=torch.uint8, device="cuda") for _ in range(8)]
+count = [0]
+
+
+def depth_on_caller_stream(I, f):
+    i = count[0] % 8
+    count[0] += 1
+    I.set_input_stream(side.cuda_stream)
+    with torch.cuda.stream(side):
+        dd[i].copy_(f[1].view(-1), non_blocking=True)
+        cc[i].copy_(rgba_img.view(-1), non_blocking=True)
+    I.integrate_depth_dev(f[0], dd[i].data_ptr(), cc[i].data_ptr(), 640, 480, K)
+
+
+run("device images copied on the caller's stream", depth_on_caller_stream, pinned_d)
 run("pinned xyz only", lambda I, f: I.integrate_points_async(f[0], f[1].data_ptr(), None, f[1].shape[0]), pinned)
+
+# ---- C: resident frames with unrelated H2D traffic beside them (does a transfer by itself slow the kernels?) ------------------
+if os.environ.get("PROBE_BACKGROUND"):
+    import threading
+    stop = False
+    copied = [0]
+    side = torch.cuda.Stream()
+    bsrc = [torch.empty(4915200, dtype=torch.uint8).pin_memory() for _ in range(4)]
+    bdst = [torch.empty(4915200, dtype=torch.uint8, device="cuda") for _ in range(4)]
+
+    def background():
+        ev = [torch.cuda.Event() for _ in range(4)]
+        i = 0
+        while not stop:
+            with torch.cuda.stream(side):
+                if i >= 4:
+                    ev[i % 4].synchronize()
+                bdst[i % 4].copy_(bsrc[i % 4], non_blocking=True)
+                ev[i % 4].record(side)
+            i += 1
+            copied[0] = i
+    th = threading.Thread(target=background)
+    th.start()
+    time.sleep(0.05)
+    c0, t0 = copied[0], time.perf_counter()
+    run("resident, 4.9 MB H2D copies running beside it on a stream of their own", lambda I, f: I.integrate_points_dev(f[0], f[1].data_ptr(), f[2].data_ptr(), f[3]), dev)
+    print(f"  background copies: {(copied[0] - c0) / (time.perf_counter() - t0):.0f} /s", flush=True)
+    stop = True
+    th.join()
+    torch.cuda.synchronize()

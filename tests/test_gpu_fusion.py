@@ -84,7 +84,12 @@ def test_simple_full_frame_5cm_parity(hip, oracle):
 
 
 @pytest.mark.parametrize("select", ["COX_APPLY=pieces", "COX_APPLY=records", "COX_PARTITION=records", "COX_PARTITION=records,COX_BUCKETS=1",
-                                    "COX_PARTITION=pieces", "COX_BUCKETS=0"])
+                                    "COX_PARTITION=pieces", "COX_BUCKETS=0",
+                                    # round 3, piece partition: large tiles classified chunk by chunk (k_big_tiles / k_big_classify; chunks of
+                                    # 1024 records so that test-sized clouds have tiles of more than two chunks), a wave per small tile
+                                    # (k_apply_wave<256> / <512>), and each of the two switched off
+                                    "COX_PARTITION=pieces,COX_BIG_CHUNK=1024,COX_WAVE_TILE_MAX=256", "COX_PARTITION=pieces,COX_BIG_CHUNK=1024",
+                                    "COX_PARTITION=pieces,COX_SPLIT_TILES=0", "COX_PARTITION=pieces,COX_APPLY_WAVE=0"])
 @pytest.mark.parametrize("voxel,sub", [(0.10, 1), (0.05, 1), (0.02, 3)])
 def test_alternative_layer_update_paths_are_bit_identical(hip, oracle, monkeypatch, select, voxel, sub):
     """Environment switches (read when an integrator is created) select the other implementations of the layer-update half of
@@ -103,6 +108,26 @@ def test_alternative_layer_update_paths_are_bit_identical(hip, oracle, monkeypat
     compare_stats(sa, sb)
     rep = compare_layers(la, lb)
     print(select, voxel, rep)
+    assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
+
+
+def test_large_tiles_are_split_and_still_bit_identical(hip, oracle, monkeypatch):
+    """Every ray of a frame leaves from the sensor, so the tiles around it hold a large part of the frame's records; with the piece
+    partition their classification is cut into chunks for the whole chip (k_big_tiles / k_big_classify) and their workgroup starts
+    from the chunks' sums.  The path must actually be taken here (cox_integrator_update_stats), with and without hard voxels in such
+    tiles (second pass over the same frames: the tiles around the sensor then hold observed voxels), and equal the oracle bit for bit."""
+    monkeypatch.setenv("COX_PARTITION", "pieces")
+    monkeypatch.setenv("COX_BIG_CHUNK", "1024")
+    frames = [0, 1, 2, 0, 1, 2]
+    la, ia, sa = run_frames(hip, method="merged", voxel=0.02, frames=frames, subsample=3, capacity_blocks=40000)
+    split = ia.update_stats()
+    monkeypatch.delenv("COX_PARTITION")
+    monkeypatch.delenv("COX_BIG_CHUNK")
+    assert split["split_tiles"] > 0 and split["chunks"] > 2 * split["split_tiles"], split
+    lb, _, sb = run_frames(oracle, method="merged", voxel=0.02, frames=frames, subsample=3, capacity_blocks=40000)
+    compare_stats(sa, sb)
+    rep = compare_layers(la, lb)
+    print(split, rep)
     assert rep["bitexact_d"] and rep["bitexact_w"] and rep["n_diff_color"] == 0, rep
 
 
