@@ -162,17 +162,35 @@ struct BigTiles {
   uint2* chunks;  // (tile, first record)
   u32 chunk_cap;
   u32 chunk;      // records per chunk; tiles of more than 2 * chunk records are split
+  u32* list;      // the tiles k_apply_block takes (more than wave_max records), in no particular order: cnt->n_block_tiles of them
+  u32 wave_max;   // largest tile k_apply_wave takes
 };
 __global__ void __launch_bounds__(256) k_big_tiles(const u32* __restrict__ tile_beg, const u32* __restrict__ tile_end, const int4* __restrict__ ord_info, Counters* cnt,
                                                    BigTiles B) {
   const u32 n_tiles = ((cnt->err & kErrRecords) ? 0u : cnt->n_touched) * kTilesPerBlock;
-  for (u32 tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_tiles; tile += gridDim.x * blockDim.x) {
-    const u32 beg = tile_beg[tile], end = tile_end[tile];
-    if (end <= beg || end - beg <= 2u * B.chunk) continue;
+  const u32 lane = threadIdx.x & 63u, stride = gridDim.x * blockDim.x;
+  for (u32 t0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < n_tiles; t0 += stride) {  // (wave-uniform bounds: the ballot below)
+    const u32 tile = t0 + lane;
+    u32 beg = 0, end = 0;
+    if (tile < n_tiles) {
+      beg = tile_beg[tile];
+      end = tile_end[tile];
+    }
+    const u32 n = end > beg ? end - beg : 0u;
+    // k_apply_block's list: the tiles too large for a wave, one atomic per wave that has any (one word takes ~88 atomics / us)
+    const bool listed = n > B.wave_max;
+    const u64 m = __ballot(listed);
+    if (m) {
+      u32 base = 0;
+      if (lane == static_cast<u32>(__ffsll(static_cast<long long>(m))) - 1u) base = atomicAdd(&cnt->n_block_tiles, static_cast<u32>(__popcll(m)));
+      base = static_cast<u32>(__shfl(static_cast<int>(base), __ffsll(static_cast<long long>(m)) - 1, 64));
+      if (listed) B.list[base + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)))] = tile;
+    }
+    if (n <= 2u * B.chunk) continue;
     if (static_cast<u32>(ord_info[tile >> kSlabBits].w) == kInvalid) continue;  // (k_apply_block skips such a tile: nobody would take the slot back)
     const u32 slot = atomicAdd(&cnt->n_big_tiles, 1u);
     if (slot >= kBigCap) continue;
-    const u32 nch = (end - beg + B.chunk - 1u) / B.chunk;
+    const u32 nch = (n + B.chunk - 1u) / B.chunk;
     const u32 base = atomicAdd(&cnt->n_big_chunks, nch);
     const bool fits = base + nch <= B.chunk_cap;  // (always: the list holds records / kBigChunkMin + kBigCap entries)
     if (fits) B.of_tile[tile] = slot + 1u;
@@ -270,8 +288,10 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
   u32 my_updates = 0, my_voxels = 0, my_maxrun = 0;
   // kBucket (records partitioned in one pass by tile id & 4095): a unit is a bucket; the tiles unit, unit + 4096, ... share its
   // record range and are taken in turn, each looking at its own records only.  Otherwise a unit is a tile.
-  const u32 n_units = kBucket ? min(n_tiles, 4096u) : n_tiles;
-  for (u32 unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+  const bool listed = !kBucket && big.list != nullptr;
+  const u32 n_units = kBucket ? min(n_tiles, 4096u) : listed ? min(cnt->n_block_tiles, n_tiles) : n_tiles;
+  for (u32 ui = blockIdx.x; ui < n_units; ui += gridDim.x) {
+    const u32 unit = listed ? big.list[ui] : ui;
     const u32 beg = tile_beg[unit], end = tile_end[unit];
     if (end <= beg) continue;  // (uniform) no record touches this slab of the block
     if (!kBucket && end - beg < min_records) continue;  // (uniform) a small tile: k_apply_wave's

@@ -76,6 +76,7 @@ struct Counters {  // per-frame device counters, zeroed at frame start
   u32 n_piece_slots;   // piece path: sum of the rays' piece bounds = slots of the piece arrays in use
   u32 n_expanded;      // piece partition: records written by k_piece_expand (what k_apply_block reads)
   u32 n_big_tiles, n_big_chunks;  // tiles whose phase 1 is split over the chip (k_big_tiles), and their chunks
+  u32 n_block_tiles;              // tiles too large for k_apply_wave: k_apply_block's list
   FastCtl fast;
   // One word takes ~88 atomics/us on this chip, so counters that every wave or workgroup of a large grid adds to
   // are sharded over 64 cache lines (index = workgroup or wave id & 63) and summed by the host.
@@ -1239,6 +1240,7 @@ struct RecordSet {  // lives B1 .. B2
   int4* ord_info = nullptr;      // [layer ht_cap] (16 * block index, pool index) per block touched this frame
   u32 *blk_beg = nullptr, *blk_end = nullptr;  // [layer ht_cap * 16] record range of every tile (block apply); zero between frames
   u32 *big_of_tile = nullptr, *big_acc = nullptr;  // large tiles (cox_apply_tile.hpp: BigTiles); zero between frames
+  u32* blk_list = nullptr;                         // [layer ht_cap * 16] tiles k_apply_block takes
   uint2* big_chunks = nullptr;
   u32 big_chunk_cap = 0;
   SortInfo* sort_info = nullptr;
@@ -1954,7 +1956,7 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
     if (!I->piece_sort)  // (piece partition: the ranges come with the expansion, k_piece_tile_ranges)
       hipLaunchKernelGGL(k_block_starts, dim3(1024), dim3(256), 0, s, V, S.blk_beg, S.blk_end, F.cnt, I->tile_shift, I->bucket_partition ? 4095u : 0xFFFFFFFFu);
     u32 min_records = 0;
-    BigTiles big{nullptr, nullptr, nullptr, 0, 0};
+    BigTiles big{nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
 #define COX_LAUNCH_APPLY(Q, TS, BUCKET)                                                                                                                       \
   hipLaunchKernelGGL((k_apply_block<Q, TS, BUCKET>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, L, S.ord_info, V, S.blk_beg, S.blk_end, F.cnt, \
                      I->layer->d_err, I->layer->h_nblocks, min_records, big)
@@ -1967,7 +1969,7 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
           min_records = I->wave_tile_max + 1;
           if (const char* e = std::getenv("COX_DEBUG_BLOCK_MIN")) min_records = static_cast<u32>(std::atoi(e));  // (timing experiments: drops tiles)
           if (I->split_big_tiles && S.big_chunks) {
-            big = BigTiles{S.big_of_tile, S.big_acc, S.big_chunks, S.big_chunk_cap, I->big_chunk};
+            big = BigTiles{S.big_of_tile, S.big_acc, S.big_chunks, S.big_chunk_cap, I->big_chunk, S.blk_list, I->wave_tile_max};
             hipLaunchKernelGGL(k_big_tiles, dim3(512), dim3(256), 0, s, S.blk_beg, S.blk_end, S.ord_info, F.cnt, big);
             hipLaunchKernelGGL((k_big_classify<true>), dim3(I->grid_apply), dim3(kBT), 0, s, F.d_params, F.rays, S.ord_info, V, S.blk_end, F.cnt, big);
           }
@@ -2199,6 +2201,7 @@ static int follow_layer(cox_integrator* I) {
       COX_HIP(hipMemset(S.blk_end, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
       if (I->piece_sort) {
         COX_TRY(dev_realloc(&S.big_of_tile, static_cast<size_t>(Lh->ht_cap) * kTilesPerBlock));
+        COX_TRY(dev_realloc(&S.blk_list, static_cast<size_t>(Lh->ht_cap) * kTilesPerBlock));
         COX_HIP(hipMemset(S.big_of_tile, 0, sizeof(u32) * Lh->ht_cap * kTilesPerBlock));
       }
       COX_HIP(hipDeviceSynchronize());
@@ -2619,6 +2622,7 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
       st = COX_ERR_NO_DEVICE;
     if (st == COX_OK && I->piece_sort) {
       st = dev_realloc(&S.big_of_tile, static_cast<size_t>(layer->ht_cap) * kTilesPerBlock);
+      if (st == COX_OK) st = dev_realloc(&S.blk_list, static_cast<size_t>(layer->ht_cap) * kTilesPerBlock);
       if (st == COX_OK) st = dev_realloc(&S.big_acc, static_cast<size_t>(kBigCap) * 2 * kTileVox);
       if (st == COX_OK && (hipMemset(S.big_of_tile, 0, sizeof(u32) * layer->ht_cap * kTilesPerBlock) != hipSuccess ||
                            hipMemset(S.big_acc, 0, sizeof(u32) * kBigCap * 2 * kTileVox) != hipSuccess))
@@ -2748,7 +2752,7 @@ void cox_integrator_destroy(cox_integrator_t* I) {
   for (RecordSet& S : I->rs) {
     for (void* p : {static_cast<void*>(S.rec_key[0]), static_cast<void*>(S.rec_key[1]), static_cast<void*>(S.rec_ray[0]), static_cast<void*>(S.rec_ray[1]),
                     static_cast<void*>(S.piece_front), static_cast<void*>(S.piece_back), static_cast<void*>(S.piece_wsum), static_cast<void*>(S.touched_slots), static_cast<void*>(S.ord_info),
-                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end), static_cast<void*>(S.big_of_tile), static_cast<void*>(S.big_acc),
+                    static_cast<void*>(S.blk_beg), static_cast<void*>(S.blk_end), static_cast<void*>(S.big_of_tile), static_cast<void*>(S.big_acc), static_cast<void*>(S.blk_list),
                     static_cast<void*>(S.big_chunks), static_cast<void*>(S.lin8), static_cast<void*>(S.pkey[0]),
                     static_cast<void*>(S.pkey[1]), static_cast<void*>(S.pstart[0]), static_cast<void*>(S.pstart[1]), static_cast<void*>(S.prl[0]),
                     static_cast<void*>(S.prl[1]), static_cast<void*>(S.pbkey), static_cast<void*>(S.plen), static_cast<void*>(S.pdest),

@@ -7,7 +7,7 @@ set -e
 OUT="$PWD/gpurun_out/${1:-r2prof}"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-COMMON="--cpu-frames 0 --reg-iters 8 --other-frames 0 --other-config-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
+COMMON="--cpu-frames 0 --reg-iters 0 --other-frames 0 --other-config-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
 echo "bench line done"
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_line_driver.json" 2> "$OUT/bench_line_driver.err"

@@ -15,7 +15,7 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 HERE = os.path.dirname(os.path.abspath(__file__))
-COMMON = "--cpu-frames 0 --reg-iters 8 --other-frames 0 --other-config-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
+COMMON = "--cpu-frames 0 --reg-iters 0 --other-frames 0 --other-config-frames 0 --pcie-frames 0 --no-profile-pass --no-ramp"
 FRAMES_TRACE = 320   # warmup 20 + steps 300
 FRAMES_PMC = 40      # the last 40 of the 80 frames (--warmup 20 --steps 60 --no-ramp): steady state
 
