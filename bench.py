@@ -211,9 +211,10 @@ def main():
                 si.sync()
         si.sync()
 
-    def run_stream(method, steps, warmup, dev, cfg_, voxel, events=0):
+    def run_stream(method, steps, warmup, dev, cfg_, voxel, events=0, collective=True):
         """warm-up + `steps` timed frames on a fresh layer; barrier + device sync on both sides, MAX over ranks.  events = n > 0:
-        HIP-event markers around the kernel classes of every n-th frame (a pass of its own: never the run `value` comes from)."""
+        HIP-event markers around the kernel classes of every n-th frame (a pass of its own: never the run `value` comes from).
+        collective=False: a pass that only rank 0 makes (no barrier, no reduction)."""
         layer = Layer(eng, voxel, device=local_rank, capacity_blocks=32768)
         integ = Integrator(eng, layer, cfg_, method)
         if events:
@@ -226,7 +227,7 @@ def main():
         integ.class_times(reset=True)
         integ.host_time(reset=True)
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and collective:
             dist.barrier()
         t0 = time.perf_counter()
         for i in range(warmup, warmup + steps):
@@ -236,10 +237,10 @@ def main():
                 integ.sync()
         integ.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and collective:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 and collective:
             tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -302,7 +303,7 @@ def main():
             live, every = None, 0
             if events:
                 every = 2 if steps < 64 else 8
-                _, _, _, live = run_stream(method, steps, warmup, dev, cfg_, voxel, events=every)
+                _, _, _, live = run_stream(method, steps, warmup, dev, cfg_, voxel, events=every, collective=False)  # (rank 0 only)
             roof, fstats, crit, ab, fst = roofline_of(method, steps, warmup, dev, cfg_, voxel, live, every)
             roof["whole_frame_algorithmic_GBps"] = ab / (dt / steps) / 1e9
             out.update({"roofline": roof, "frame_stats_mean": fstats, "critical_path": crit})
