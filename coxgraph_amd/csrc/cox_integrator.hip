@@ -2040,7 +2040,6 @@ static int stage_apply(const StageCtx& c, hipStream_t s) {
         else if (I->wave_apply) {  // fine voxels (cox_apply_tile.hpp): the largest tiles classified chunk by chunk by the whole chip, a
                                    // workgroup per tile for the large ones, a wave per tile for the rest
           min_records = I->wave_tile_max + 1;
-          if (const char* e = std::getenv("COX_DEBUG_BLOCK_MIN")) min_records = static_cast<u32>(std::atoi(e));  // (timing experiments: drops tiles)
           if (I->split_big_tiles && S.big_chunks) {
             big = BigTiles{S.big_of_tile, S.big_acc, S.big_chunks, S.big_chunk_cap, I->big_chunk, S.blk_list, I->wave_tile_max};
             hipLaunchKernelGGL(k_big_tiles, dim3(512), dim3(256), 0, s, S.blk_beg, S.blk_end, S.ord_info, F.cnt, big);
