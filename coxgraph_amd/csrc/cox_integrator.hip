@@ -517,14 +517,13 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
         float n_lo = 1.0f, n_hi = 1.0f;
         // groups of 4 steps with the next group's operands already in flight: the LDS latency (~100 cycles) would
         // otherwise bound every step of the chain
+        // Two register sets in turn (eight steps per round): the operands of one group of four are read from LDS while the other
+        // group's steps run, with scheduling barriers so that the reads are issued where they are written -- left alone, the compiler
+        // moves each group's first read to the top of its own steps and waits for it there (~100 cycles per four steps on the chain).
+        // Rows beyond the chunk are the identity, so a trailing group of four is harmless.
         MergeOp a0 = tbl[0][role], a1 = tbl[1][role], a2 = tbl[2][role], a3 = tbl[3][role];
-        for (u32 k = 0; k < cnt_in; k += 4) {
-          const MergeOp o0 = a0, o1 = a1, o2 = a2, o3 = a3;
-          const u32 kn = (k + 4) & 63u;
-          a0 = tbl[kn][role];
-          a1 = tbl[kn + 1][role];
-          a2 = tbl[kn + 2][role];
-          a3 = tbl[kn + 3][role];
+        // (Going on with q1 and checking off the chain that the second correction would not have changed it does not pay: one step
+        // in a hundred needs that correction, so nearly every chunk of 3 x 64 steps had to be redone.)
 #define COX_MERGE_STEP(op)                                  \
   {                                                         \
     const float N = val * (op).x + (op).y;                  \
@@ -536,12 +535,28 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
     const float e1 = __builtin_fmaf(-(op).z, q1, N);        \
     val = __builtin_fmaf(e1, (op).w, q1);                   \
   }
-          COX_MERGE_STEP(o0)
-          COX_MERGE_STEP(o1)
-          COX_MERGE_STEP(o2)
-          COX_MERGE_STEP(o3)
-#undef COX_MERGE_STEP
+        for (u32 k = 0; k < cnt_in; k += 8) {
+          const u32 kb = (k + 4) & 63u;
+          const MergeOp b0 = tbl[kb][role], b1 = tbl[kb + 1][role], b2 = tbl[kb + 2][role], b3 = tbl[kb + 3][role];
+          __builtin_amdgcn_sched_barrier(0);
+          COX_MERGE_STEP(a0)
+          COX_MERGE_STEP(a1)
+          COX_MERGE_STEP(a2)
+          COX_MERGE_STEP(a3)
+          __builtin_amdgcn_sched_barrier(0);
+          const u32 ka = (k + 8) & 63u;
+          a0 = tbl[ka][role];
+          a1 = tbl[ka + 1][role];
+          a2 = tbl[ka + 2][role];
+          a3 = tbl[ka + 3][role];
+          __builtin_amdgcn_sched_barrier(0);
+          COX_MERGE_STEP(b0)
+          COX_MERGE_STEP(b1)
+          COX_MERGE_STEP(b2)
+          COX_MERGE_STEP(b3)
+          __builtin_amdgcn_sched_barrier(0);
         }
+#undef COX_MERGE_STEP
         const bool bad = (lane < 3) && !(n_lo >= 9.094947e-13f && n_hi <= 1.0995116e12f);  // NaN fails too
         if (__ballot(bad || !d_ok)) {
           val = val_in;
@@ -553,19 +568,38 @@ __global__ void __launch_bounds__(256) k_bundle_merge(const FrameParams* __restr
           }
         }
       } else {
+        // (the same two register sets in turn; the identity rows leave an integer as it is)
+        // roundf(x) for x >= 0 (a blend of non-negative values with non-negative factors): trunc(x), plus one where the -- exactly
+        // computed -- fraction reaches a half; two dependent operations fewer than the sign-preserving general form.
+#define COX_COLOUR_STEP(op)                                 \
+  {                                                         \
+    const float x = val * (op).x + (op).y;                  \
+    const float t = truncf(x);                              \
+    val = (x - t >= 0.5f) ? t + 1.0f : t;                   \
+  }
         MergeOp a0 = tbl[0][role], a1 = tbl[1][role], a2 = tbl[2][role], a3 = tbl[3][role];
-        for (u32 k = 0; k < cnt_in; k += 4) {
-          const MergeOp o0 = a0, o1 = a1, o2 = a2, o3 = a3;
-          const u32 kn = (k + 4) & 63u;
-          a0 = tbl[kn][role];
-          a1 = tbl[kn + 1][role];
-          a2 = tbl[kn + 2][role];
-          a3 = tbl[kn + 3][role];
-          val = roundf(val * o0.x + o0.y);
-          val = roundf(val * o1.x + o1.y);
-          val = roundf(val * o2.x + o2.y);
-          val = roundf(val * o3.x + o3.y);
+        for (u32 k = 0; k < cnt_in; k += 8) {
+          const u32 kb = (k + 4) & 63u;
+          const MergeOp b0 = tbl[kb][role], b1 = tbl[kb + 1][role], b2 = tbl[kb + 2][role], b3 = tbl[kb + 3][role];
+          __builtin_amdgcn_sched_barrier(0);
+          COX_COLOUR_STEP(a0)
+          COX_COLOUR_STEP(a1)
+          COX_COLOUR_STEP(a2)
+          COX_COLOUR_STEP(a3)
+          __builtin_amdgcn_sched_barrier(0);
+          const u32 ka = (k + 8) & 63u;
+          a0 = tbl[ka][role];
+          a1 = tbl[ka + 1][role];
+          a2 = tbl[ka + 2][role];
+          a3 = tbl[ka + 3][role];
+          __builtin_amdgcn_sched_barrier(0);
+          COX_COLOUR_STEP(b0)
+          COX_COLOUR_STEP(b1)
+          COX_COLOUR_STEP(b2)
+          COX_COLOUR_STEP(b3)
+          __builtin_amdgcn_sched_barrier(0);
         }
+#undef COX_COLOUR_STEP
       }
       wave_lds_handover();
       W = readlane_f32(Wnext, cnt_in - 1);
