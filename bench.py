@@ -29,6 +29,7 @@ of SURVEY.md section 8d (16 B per valid point + 24 B per touched voxel); `cpu_ba
 reference's configured integrator (fast, 8 threads) on a bounded sample of the same frames on this box's host cores.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -189,6 +190,10 @@ def main():
         return host, dev
 
     host_frames, dev_frames = make_frames(n_frames, W, H, keep_host)
+    # The interpreter's cyclic collector stays off from here on and is run by hand between the legs: a full collection that happens to
+    # fall into a timed region is a 40 ms hole in 3-30 ms of frames (seen at 10 cm: 4 950 frames/s read as 1 700; which leg it hits
+    # depends on how many objects the clock ramp before it allocated, i.e. on how fast the GPU is).
+    gc.disable()
 
     def config_for(voxel):
         return eng.default_config(**synth.integrator_overrides(voxel))
@@ -227,14 +232,20 @@ def main():
         integ.class_times(reset=True)
         integ.host_time(reset=True)
         torch.cuda.synchronize()
+        gc.collect()   # (the collector is off for the whole run -- main() -- and runs here, between the legs)
         if world > 1 and collective:
             dist.barrier()
         t0 = time.perf_counter()
+        marks = []
         for i in range(warmup, warmup + steps):
             T, xyz, rgba, n = dev[i]
             integ.integrate_points_dev(T, xyz.data_ptr(), rgba.data_ptr(), n)
             if args.serial:
                 integ.sync()
+            if os.environ.get("BENCH_DEBUG") and (i - warmup) % 10 == 9:
+                marks.append(round((time.perf_counter() - t0) * 1e3, 2))
+        if marks:
+            print("[bench debug] ms at every 10th enqueue:", marks, file=sys.stderr, flush=True)
         integ.sync()
         torch.cuda.synchronize()
         if world > 1 and collective:
@@ -415,6 +426,7 @@ def main():
                 call(integ, f)
             integ.sync()
             torch.cuda.synchronize()
+            gc.collect()
             t0 = time.perf_counter()
             for f in frames[nw:nw + nf]:
                 call(integ, f)
