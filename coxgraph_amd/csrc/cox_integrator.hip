@@ -1455,6 +1455,8 @@ void cox_drain_submitters() {
 struct cox_integrator {
   Submitter* submitter = nullptr;  // COX_SUBMIT_THREAD=0 turns it off
   CopyPool* copy_pool = nullptr;   // helpers for the bounce copy of pageable inputs: created with the first such frame
+  bool h2d_kernel = false;         // COX_H2D=kernel: pinned inputs read by a copy kernel of h2d_groups workgroups instead of the copy engine
+  int h2d_groups = 8;
   uint64_t last_big_tiles = 0, last_big_chunks = 0;  // of the last frame whose counters were folded (cox_integrator_update_stats)
   uint64_t host_ns = 0, host_wait_ns = 0, host_frames = 0;  // time the caller's thread spends inside the integrate call (enqueueing, waiting for a free slot)
   cox_projective* proj = nullptr;  // method == COX_METHOD_PROJECTIVE: everything else below stays empty
@@ -2593,6 +2595,8 @@ int cox_integrator_create(cox_layer_t* layer, const cox_tsdf_config* cfg, int me
   if (const char* e = std::getenv("COX_GRID_APPLY_WAVE")) I->grid_apply_wave = static_cast<u32>(std::max(8, std::atoi(e)));
   if (const char* e = std::getenv("COX_APPLY_WAVE")) I->wave_apply = std::atoi(e) != 0;
   if (const char* e = std::getenv("COX_SPLIT_TILES")) I->split_big_tiles = std::atoi(e) != 0;
+  I->h2d_kernel = std::getenv("COX_H2D") && std::string(std::getenv("COX_H2D")) == "kernel";
+  I->h2d_groups = std::getenv("COX_H2D_GROUPS") ? std::max(1, std::atoi(std::getenv("COX_H2D_GROUPS"))) : kCopyGroups;
   if (const char* e = std::getenv("COX_BIG_CHUNK")) I->big_chunk = static_cast<u32>(std::max<int>(kBigChunkMin, std::atoi(e)));
   if (const char* e = std::getenv("COX_WAVE_TILE_MAX")) I->wave_tile_max = std::atoi(e) == 256 ? 256u : 512u;
   if (const char* e = std::getenv("COX_GRID_MERGE")) I->grid_merge = std::max(1, std::atoi(e));
@@ -2927,10 +2931,10 @@ static const void* host_pointer_device_view(const void* p) {
   return a.devicePointer ? a.devicePointer : p;
 }
 // one or two arrays (bytes a multiple of 4) from pinned host memory, seen by the device at src_dev_*, to dst_* on stream s
-static int copy_pinned_to_device(void* dst_a, const void* src_a, const void* src_dev_a, size_t bytes_a, void* dst_b, const void* src_b, const void* src_dev_b,
-                                 size_t bytes_b, hipStream_t s) {
-  static const bool use_memcpy = !(std::getenv("COX_H2D") && std::string(std::getenv("COX_H2D")) == "kernel");
-  static const int groups = std::getenv("COX_H2D_GROUPS") ? std::max(1, std::atoi(std::getenv("COX_H2D_GROUPS"))) : kCopyGroups;
+static int copy_pinned_to_device(const cox_integrator* I, void* dst_a, const void* src_a, const void* src_dev_a, size_t bytes_a, void* dst_b, const void* src_b,
+                                 const void* src_dev_b, size_t bytes_b, hipStream_t s) {
+  const bool use_memcpy = !I->h2d_kernel;
+  const int groups = I->h2d_groups;
   auto unaligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
   const bool two = dst_b != nullptr;
   if (use_memcpy || !src_dev_a || unaligned(src_dev_a) || unaligned(dst_a) || (bytes_a & 3u) ||
@@ -3003,7 +3007,7 @@ static int stage_host_inputs(cox_integrator* I, int k, const void* a, size_t a_b
     dev_a = host_pointer_device_view(src_a);
     dev_b = b ? host_pointer_device_view(src_b) : nullptr;
   }
-  COX_TRY(copy_pinned_to_device(dst_a, src_a, dev_a, a_bytes * n, b ? dst_b : nullptr, src_b, dev_b, b ? b_bytes * n : 0, s_in));
+  COX_TRY(copy_pinned_to_device(I, dst_a, src_a, dev_a, a_bytes * n, b ? dst_b : nullptr, src_b, dev_b, b ? b_bytes * n : 0, s_in));
   COX_HIP(hipEventRecord(I->in_ready[k], s_in));
   I->in_used[k] = true;
   in->ready = I->st_in ? I->in_ready[k] : nullptr;  // (without an input stream: same stream as the frame's first stage, stream order)

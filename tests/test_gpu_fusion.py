@@ -650,17 +650,23 @@ def test_fast_relaxation_on_the_device_and_its_sequential_fallback(hip, oracle, 
 
 
 @pytest.mark.parametrize("method", ["merged", "fast", "simple"])
-@pytest.mark.parametrize("pinned", [False, True])
-def test_async_host_entry_equals_the_synchronous_one(hip, method, pinned):
-    """cox_integrate_points_async: host buffers, frames not waited for (H2D of frame t+1 beside the kernels of frame t, three staging
-    sets reused many times), from pageable memory (bounce buffer) and from pinned memory (copied from directly)."""
+@pytest.mark.parametrize("pinned,select", [(False, ""), (True, ""), (True, "COX_INPUT_STREAM=0"), (True, "COX_H2D=kernel"), (False, "COX_COPY_THREADS=0")])
+def test_async_host_entry_equals_the_synchronous_one(hip, monkeypatch, method, pinned, select):
+    """cox_integrate_points_async: host buffers, frames not waited for (H2D of frame t+1 on the input stream beside the kernels of
+    frame t, six staging sets reused many times), from pageable memory (bounce buffer, copied by the caller and three helper threads)
+    and from pinned memory (copied from directly); and the switches: copies on the frame's own stream, a copy kernel instead of the copy
+    engine, the bounce copy by the caller alone."""
     import torch
     sub = 2 if method != "simple" else 13
     n_frames = 30
     frames = [synth.make_frame(t) for t in range(n_frames)]
     cfg = hip.default_config(integrator_threads=1, **synth.integrator_overrides(0.05))
     a, b = Layer(hip, 0.05, capacity_blocks=16384), Layer(hip, 0.05, capacity_blocks=16384)
-    ia, ib = Integrator(hip, a, cfg, method), Integrator(hip, b, cfg, method)
+    env = dict(kv.split("=") for kv in select.split(",")) if select else {}
+    for name, value in env.items():
+        monkeypatch.setenv(name, value)   # (read when the integrator is created / at its first host frame)
+    ia = Integrator(hip, a, cfg, method)
+    ib = Integrator(hip, b, cfg, method)
     host = []
     for T, p, c, _ in frames:
         xyz, rgba = torch.from_numpy(np.ascontiguousarray(p[::sub])), torch.from_numpy(np.ascontiguousarray(c[::sub]))
