@@ -4,7 +4,7 @@
 // ---- block apply: the TSDF update with the voxel tiles staged in LDS -----------------------------------------------------
 // The records arrive PARTITIONED by tile = (block ordinal, z-slab of the block: 16 x 16 x 1 voxels = 256 voxels, 3 KB of
 // contiguous wire words) -- one or two stable radix passes on those bits; ray order inside a tile is preserved.  One
-// workgroup owns one tile (a 16^3 block is sixteen of them; a frame at 5 cm has ~10^3 tiles with records, at 1 cm ~10^5,
+// workgroup owns one tile (a 16^3 block is sixteen of them; a frame at 5 cm has ~10^3 tiles with records, at 1 cm ~2 * 10^4,
 // so the chip is full at every voxel size, and the near-camera blocks that every ray crosses are spread over 16 workgroups):
 //   0. the tile's voxels are read into LDS with full-line loads;
 //   1. every record of the tile is evaluated once (voxel centre, sdf, update weight) and classified: a SATURATING record
@@ -146,9 +146,10 @@ __device__ __forceinline__ float sdf_of_record(const FrameParams& P, const RayOf
 }
 
 // ---- large tiles: phase 1 by the whole chip ------------------------------------------------------------------------------------
-// The rays of a frame all leave from the sensor: the tiles around it are crossed by every ray (1 cm: 2 * 10^6 of the frame's 2.5 * 10^7
-// records in ONE tile), and k_apply_block gives a tile to one workgroup -- its duration was that tile's, 0.8 ms, whatever the other
-// 10^5 tiles cost (which is why neither larger tiles nor a wave per small tile changed it).  Phase 1 is a sum: saturating weights and
+// The rays of a frame all leave from the sensor: the tiles around it are crossed by every ray (1 cm: 320 of a frame's 2 * 10^4 tiles
+// have more than 8 192 records and hold up to 29 % of its 2.8 * 10^7 records), and k_apply_block gives a tile to one workgroup -- its
+// duration was the largest tile's, 0.8 ms, whatever the others cost (which is why neither larger tiles nor a wave per small tile
+// changed it).  Phase 1 is a sum: saturating weights and
 // record counts per voxel, exact in any order.  So the tiles of more than two chunks (of kBigChunk records) are cut into chunks,
 // every chunk is classified by a workgroup of its own into LDS and added to the tile's accumulators in global memory (integer
 // atomics), and k_apply_block starts such a tile from those instead of running over its records.  Phases 2-4 are unchanged -- a voxel
@@ -447,7 +448,7 @@ __global__ void __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 
 // ---- wave apply: k_apply_block's four phases, ONE WAVE per small tile (fine voxels) ---------------------------------------------
-// At fine voxels a frame has ~10^5 tiles of a few hundred records each (1 cm: 2.5 * 10^7 records over 10^5 tiles), and a tile is a
+// At fine voxels a frame has ~2 * 10^4 tiles, most of them of a few hundred records (1 cm: 2.8 * 10^7 records in all), and a tile is a
 // chain of dependent global round trips -- range -> block info -> voxels, records -> ray lines -> (hard voxels) records again -> ray
 // lines, colours -- with a workgroup barrier between the phases.  With a 512-thread workgroup per tile a CU has FOUR tiles in flight and
 // half the lanes of phase 1 have no record; the kernel is bound by that chain (0.8 ms at 1 cm for ~0.1 ms worth of instructions and
