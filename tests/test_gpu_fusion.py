@@ -441,7 +441,7 @@ def test_async_device_path_equals_the_synchronous_one(hip, method, sub):
     assert np.array_equal(ja, jb) and np.array_equal(va, vb)
 
 
-@pytest.mark.parametrize("env", [{"COX_STREAMS": "2"}, {"COX_STREAMS": "4s"}, {"COX_STREAMS": "6"}, {"COX_SUBMIT_THREAD": "0"}, {"COX_STREAMS": "6", "COX_SUBMIT_THREAD": "0"},
+@pytest.mark.parametrize("env", [{"COX_STREAMS": "2"}, {"COX_STREAMS": "4s"}, {"COX_STREAMS": "3p"}, {"COX_STREAMS": "6"}, {"COX_SUBMIT_THREAD": "0"}, {"COX_STREAMS": "6", "COX_SUBMIT_THREAD": "0"},
                                  {"COX_GRAPH": "1"}, {"COX_STREAM_MAP": "001234"}, {"COX_TILE": "9"}, {"COX_TILE": "9", "COX_PARTITION": "pieces"},
                                  {"COX_PARTITION": "pieces"}])
 @pytest.mark.parametrize("method", ["merged", "simple"])
