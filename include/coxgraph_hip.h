@@ -179,9 +179,10 @@ int cox_integrate_points_ex(cox_integrator_t* integ, const float T_G_C[7], const
 int cox_integrate_points_dev(cox_integrator_t* integ, const float T_G_C[7], const float* xyz_dev, const uint8_t* rgba_dev, uint64_t n, int freespace);
 /* TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace_points) as the reference calls it -- with HOST
  * buffers (coxgraph/include/coxgraph/map_comm/tsdf_recover.h:71-77) -- without waiting for the frame: the buffers are copied to
- * one of three staging sets on the stream the frame's ray generation runs on (with the default stream map the copy of frame t+1
- * runs beside the kernels of frame t) and the frame is enqueued behind the copy.  Pageable buffers are free again when the call returns (they go through a pinned bounce
- * buffer: one CPU copy); buffers in pinned memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor after pin_memory()) are
+ * one of six staging sets on the integrator's input stream (the copy of frame t+1 runs beside the kernels of frame t; the call waits
+ * on the host only when all six sets are still being read, i.e. when the caller is six frames ahead of the device) and the frame
+ * is enqueued behind the copy.  Pageable buffers are free again when the call returns (they go through a pinned bounce
+ * buffer: one CPU copy, shared with three helper threads of the integrator); buffers in pinned memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor after pin_memory()) are
  * copied from directly and must stay unmodified until cox_integrator_wait_inputs or cox_integrator_sync has returned.
  * Errors of the frame are reported by the next cox_integrator_sync, as for the *_dev entry points. */
 int cox_integrate_points_async(cox_integrator_t* integ, const float T_G_C[7], const float* xyz, const uint8_t* rgba, uint64_t n, int freespace);
