@@ -615,7 +615,12 @@ __global__ void __launch_bounds__(64) k_fast_sequential(const FrameParams* __res
 }
 // after the relaxation: the table keeps the hash of the last performed operation on each slot
 __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V0, FastVisits V1, const u32* reach, u64* __restrict__ table_obs, const FastCtl* ctl,
-                                                         u32 vcap0, u32 vcap1, u32* __restrict__ stats) {
+                                                         u32 vcap0, u32 vcap1, u32* __restrict__ stats, RayArrays R, Counters* cnt) {
+  {  // hand the rays over to the record pipeline: a ray emits its first reach[r] voxels (was a launch of its own behind this one)
+    const u32 n_rays = cnt->n_rays;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->n_ray_slots = n_rays;
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) R.nsteps[r] = reach[r];
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // run totals (cox_integrator_fast_stats): how often the relaxation was not enough, and how much of it there was
     const int last = fast_last_round(ctl);
     bool aborted = false;
@@ -676,11 +681,4 @@ __global__ void __launch_bounds__(256) k_fast_obs_commit(FastVisits V0, FastVisi
     if (last) table_obs[key] = V.shash[i];
   }
 }
-// hand the rays over to the record pipeline: a ray emits its first reach[r] voxels
-__global__ void __launch_bounds__(256) k_fast_finish(RayArrays R, const u32* __restrict__ reach, Counters* cnt) {
-  const u32 n_rays = cnt->n_rays;
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->n_ray_slots = n_rays;
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) R.nsteps[r] = reach[r];
-}
-
 }  // namespace cox

@@ -2246,9 +2246,12 @@ static int fast_solve(const StageCtx& c, const FastJob& job) {
     // that have outgrown their lists since
     TimedRegion t(I, COX_KC_FAST_ROUND1, s);
     hipLaunchKernelGGL(k_fast_grow, gr, dim3(256), 0, s, F.rays.nsteps, cap, reach, ctl, round, X.cap1, X.long_list, n_rays);
-    if (I->pcap <= (1u << 15)) {
+    if (I->pcap <= (1u << 15) || X.rounds == 2) {
+      // one workgroup, 4 096 rays at a time: a frame at coarse voxels starts a few thousand rays (the three-launch scan and its
+      // bookkeeping kernel were four of the solve chain's eighteen launches; a frame in which every point of a large cloud starts a ray
+      // pays 0.2 ms here instead)
       hipLaunchKernelGGL(k_fast_scan_caps, dim3(1), dim3(1024), 0, s, cap, V1.voff, ctl, round, I->pcap, V1.cap);
-    } else {  // (rays by the hundred thousand: the three-launch scan; it covers scan_n rays, none without growth)
+    } else {  // (rays by the ten thousand, fine voxels: the three-launch scan; it covers scan_n rays, none without growth)
       exclusive_scan_u32(cap, V1.voff, &ctl->scan_n[round], I->pcap, I->pcap, &ctl->n_visits[round], I->scanws_f, s);
       hipLaunchKernelGGL(k_fast_scan_caps_done, dim3(1), dim3(1), 0, s, ctl, round, V1.cap);
     }
@@ -2268,8 +2271,7 @@ static int fast_solve(const StageCtx& c, const FastJob& job) {
   // (the relaxation packs (ray, step) into one word: a configuration whose walks or ray counts do not fit takes the sequential kernel)
   const bool packed_ok = I->steps_max <= kFastStepMask && I->pcap <= (1u << (32 - kFastStepBits));
   hipLaunchKernelGGL(k_fast_sequential, dim3(1), dim3(64), 0, s, F.d_params, FF, F.rays, X.table_obs, reach, ctl, (X.force_sequential || !packed_ok) ? 1 : 0, n_rays);
-  hipLaunchKernelGGL(k_fast_obs_commit, dim3(512), dim3(256), 0, s, fast_view(V0), fast_view(V1), reach, X.table_obs, ctl, V0.cap, V1.cap, X.d_stats);
-  hipLaunchKernelGGL(k_fast_finish, gr, dim3(256), 0, s, F.rays, reach, F.cnt);
+  hipLaunchKernelGGL(k_fast_obs_commit, dim3(512), dim3(256), 0, s, fast_view(V0), fast_view(V1), reach, X.table_obs, ctl, V0.cap, V1.cap, X.d_stats, F.rays, F.cnt);
   COX_HIP(hipEventRecord(V0.done, s));
   V0.used = true;
   return COX_OK;
